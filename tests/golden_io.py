@@ -1,0 +1,22 @@
+"""Loaders for the committed golden vectors (tests/golden/, written by tests/golden/make_golden.py)."""
+import gzip
+import json
+from pathlib import Path
+
+import numpy as np
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+
+
+def unpack(flat: np.ndarray, off: np.ndarray):
+    raw = flat.tobytes()
+    return [raw[off[i]:off[i + 1]] for i in range(len(off) - 1)]
+
+
+def load_npz(name):
+    return np.load(GOLDEN / name, allow_pickle=False)
+
+
+def load_json_gz(name):
+    with gzip.open(GOLDEN / name, "rt") as f:
+        return json.load(f)
