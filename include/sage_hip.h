@@ -1,0 +1,128 @@
+/*
+ * sage_hip.h -- C-ABI of libsage_hip.so: the MI355X (gfx950) implementation of SaGe 2.0's per-iteration
+ * vocabulary-ablation hot path.
+ *
+ * The reference has NO native boundary for this path: it is a plain Python call,
+ *     run_sage_parallel(embeddings, partial_corpus, sage_model, workers_number)
+ *         -> (total_tokens, total_triples, sage_losses, ablated_sizes)
+ * (/root/reference/src/sage_tokenizer/utils.py:141-190, sole caller SaGeVocabBuilder.py:100-103).  The
+ * entry points below are what a ctypes binding for that call binds; the binding itself
+ * is sage_amd/_lib.py and INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions: every function returns 0 on success and a negative SAGE_E_* code on failure;
+ * sage_last_error(ctx) then holds a message.  All pointers are HOST pointers to caller-owned memory that is
+ * only borrowed for the duration of the call, unless the name says `_device`.  One context belongs to one
+ * GPU and one host thread at a time.  Nothing here takes or returns torch types.
+ */
+#ifndef SAGE_HIP_H
+#define SAGE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sage_ctx sage_ctx;
+
+enum {
+    SAGE_OK = 0,
+    SAGE_E_ARG = -1,         /* bad argument (null pointer, unsorted offsets, pad != 2, ...) */
+    SAGE_E_MISSING_BYTE = -2,/* a single-byte key is absent: model.py:251-255 raises Exception("missing byte") */
+    SAGE_E_HIP = -3,         /* a HIP runtime call failed */
+    SAGE_E_STATE = -4,       /* vocab / corpus / embeddings not set yet */
+    SAGE_E_LIMIT = -5,       /* a documented limit was exceeded (key longer than 32 bytes, id >= 2^20-1, ...) */
+    SAGE_E_ROW = -6,         /* a token id indexes past the embedding matrix (numpy IndexError in utils.py:133) */
+    SAGE_E_EMPTY_LINE = -7   /* an empty line: model.py:148 cannot unpack zip(*[]) */
+};
+
+/* Library version, "major.minor.patch". */
+const char* sage_version(void);
+
+/* Creates a context bound to HIP device `device` (one context per GPU / per process rank). */
+int sage_create(int device, sage_ctx** out_ctx);
+void sage_destroy(sage_ctx* ctx);
+const char* sage_last_error(const sage_ctx* ctx);
+
+/*
+ * Replaces SaGeTokenizer.set_vocabulary / set_bytes_vocab / verify_all_single_byte_exist_in_vocab
+ * (model.py:28-51, 251-255).  Key i is key_bytes[key_offsets[i] .. key_offsets[i+1]) and gets id key_ids[i]
+ * (key_ids == NULL: id = i, the reference's "position in the list").  Keys must be distinct (the Python
+ * wrapper resolves repeats the way the dict does).  All 256 single bytes must be present.  Limits: key
+ * length 1..32 bytes, ids < 2^20 - 1, max_len 1..32.
+ */
+int sage_set_vocab(sage_ctx* ctx, const uint8_t* key_bytes, const int64_t* key_offsets, const int32_t* key_ids,
+                   int64_t n_keys, int32_t max_len);
+
+/*
+ * Uploads the partial corpus once per run: line i is bytes[line_offsets[i] .. line_offsets[i+1]) exactly as
+ * `bytes(d, 'utf-8')` of utils.py:216 (trailing "\n" included).  Replaces the List[str] pickled to every
+ * worker (utils.py:156).
+ */
+int sage_set_corpus(sage_ctx* ctx, const uint8_t* bytes, const int64_t* line_offsets, int64_t n_lines);
+
+/*
+ * Uploads the [rows, dim] float64 embedding matrix of embeddings.py:77-89, row = token id.  Called once per
+ * embeddings_schedule step (SaGeVocabBuilder.py:89-91); `rows` may exceed the current vocabulary size: after a
+ * prune the re-compacted ids keep indexing the rows of the old matrix, which is the reference's behaviour.
+ */
+int sage_set_embeddings(sage_ctx* ctx, const double* emb, int64_t rows, int32_t dim);
+
+/*
+ * Replaces SaGeTokenizer.tokenize (model.py:81-101) for lines [line_begin, line_end).
+ * out_counts[i] = number of tokens of line line_begin+i.  If out_ids/out_starts/out_widths are non-NULL they
+ * receive the (id, start, width) triples of all lines back to back (capacity `capacity` triples; the call
+ * fails with SAGE_E_ARG if that is too small).  *out_total = total number of tokens.
+ */
+int sage_tokenize(sage_ctx* ctx, int64_t line_begin, int64_t line_end, int32_t* out_ids, int32_t* out_starts,
+                  int32_t* out_widths, int64_t capacity, int64_t* out_counts, int64_t* out_total);
+
+/*
+ * One ablation step: replaces run_sage_parallel -> sage_per_chunk -> fast_sage/do_triples/compute_losses
+ * (utils.py:141-257, model.py:115-248) over the lines [segment_line_bounds[0], segment_line_bounds[n_segments]).
+ * segment_line_bounds has n_segments+1 increasing line indices; each [b[s], b[s+1]) is one range over which
+ * the reference keeps one `triples` dict (a worker shard of utils.py:111-113 cut at the flush rule of
+ * utils.py:220), i.e. the scope of the distinct-key count that sums to total_triples.
+ *   out_loss[vsize]   f64: already negated like utils.py:255; 0 for ids that never occur
+ *   out_occ[vsize]    i64: number of ablated occurrences of each id (> 0 <=> the id is a key of sage_losses)
+ *   out_hist[hist_len] i64: ablated_sizes histogram, out_hist[k] = count of ablations into k tokens
+ *                       (k >= hist_len is accumulated into out_hist[hist_len-1])
+ * vsize must be > the largest id.  pad must be 2 (model.py:138; never overridden at utils.py:216).
+ */
+int sage_ablation_step(sage_ctx* ctx, const int64_t* segment_line_bounds, int64_t n_segments, int32_t pad,
+                       double* out_loss, int64_t* out_occ, int64_t vsize, int64_t* out_total_tokens,
+                       int64_t* out_total_triples, int64_t* out_hist, int64_t hist_len);
+
+/*
+ * Same step, results left in caller-provided DEVICE buffers (e.g. torch tensors that go straight into an
+ * RCCL all-reduce): d_loss f64[vsize], d_occ i64[vsize], d_hist i64[hist_len], d_totals i64[2] =
+ * {total_tokens, total_triples}.  Buffers are overwritten, not accumulated.  The call returns after the
+ * context's stream has been synchronised.
+ */
+int sage_ablation_step_device(sage_ctx* ctx, const int64_t* segment_line_bounds, int64_t n_segments, int32_t pad,
+                              double* d_loss, int64_t* d_occ, int64_t vsize, int64_t* d_totals,
+                              int64_t* d_hist, int64_t hist_len);
+
+/*
+ * Measurement hooks (no counterpart in the reference).  With profiling on, every kernel launch of the next
+ * steps is bracketed by HIP events on the context's stream; sage_get_kernel_times returns, per kernel class,
+ * the number of launches and the summed milliseconds since the last sage_reset_kernel_times.
+ */
+enum { SAGE_K_MATCH = 0, SAGE_K_WALK = 1, SAGE_K_SCAN = 2, SAGE_K_COUNT = 3, SAGE_K_SCORE = 4, SAGE_K_MISC = 5,
+       SAGE_K_NCLASSES = 6 };
+int sage_set_profiling(sage_ctx* ctx, int enabled);
+int sage_reset_kernel_times(sage_ctx* ctx);
+int sage_get_kernel_times(sage_ctx* ctx, double* out_ms /*[SAGE_K_NCLASSES]*/, int64_t* out_launches /*[SAGE_K_NCLASSES]*/);
+
+/* Tunables: scratch is sized for batches of at most `bytes` corpus bytes (default 256 MiB). */
+int sage_set_batch_bytes(sage_ctx* ctx, int64_t bytes);
+
+/* Workload statistics of the last step, for the roofline's algorithmic bytes:
+ * out[0]=tokens, out[1]=corpus bytes, out[2]=ablated occurrences, out[3]=embedding rows touched,
+ * out[4]=signed pair records, out[5]=distinct-count probes inserted. */
+int sage_get_step_stats(sage_ctx* ctx, int64_t* out /*[8]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAGE_HIP_H */

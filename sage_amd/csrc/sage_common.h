@@ -1,0 +1,45 @@
+// Shared host/device definitions for libsage_hip.so (gfx950 only).
+#pragma once
+#include <stdint.h>
+
+#define SAGE_MAX_KEY_LEN 32
+#define SAGE_ID_BITS 20
+#define SAGE_ID_MASK 0xFFFFFu
+#define SAGE_MAX_ID (SAGE_ID_MASK - 1)  // 0xFFFFF itself is reserved so that no live slot equals SAGE_SLOT_EMPTY
+#define SAGE_SLOT_EMPTY 0xFFFFFFFFu
+#define SAGE_SET_EMPTY 0xFFFFFFFFFFFFFFFFull
+
+#if defined(__HIPCC__)
+#define SAGE_HD __host__ __device__ __forceinline__
+#else
+#define SAGE_HD static inline
+#endif
+
+// FNV-1a over the key bytes followed by a 32-bit finaliser.  Prefix hashes of one text position are produced
+// incrementally: h(j) = fnv_step(h(j-1), byte[j-1]).
+#define SAGE_FNV_OFFSET 0x811C9DC5u
+SAGE_HD uint32_t sage_fnv_step(uint32_t h, uint32_t b) { return (h ^ b) * 16777619u; }
+SAGE_HD uint32_t sage_mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+// A vocab-table slot: id[0:20) | (len-1)[20:25) | tag[25:32).  A bucket is 4 slots (one 16-byte load), filled in
+// order; a bucket whose last slot is empty terminates a probe sequence.
+SAGE_HD uint32_t sage_slot_make(uint32_t id, uint32_t len, uint32_t f) {
+    return id | ((len - 1u) << 20) | ((f >> 25) << 25);
+}
+SAGE_HD uint32_t sage_slot_want(uint32_t len, uint32_t f) { return ((f >> 25) << 5) | (len - 1u); }
+
+SAGE_HD uint64_t sage_mix64(uint64_t k) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    return k;
+}
+
+// A match-table entry per corpus byte: x = id1 | len1<<20 (longest key at this byte, never crossing the line
+// end), y = id2 | len2<<20 (second longest; len2 == 0 iff len1 == 1).
+#define SAGE_M_ID(w) ((w) & SAGE_ID_MASK)
+#define SAGE_M_LEN(w) ((w) >> 20)
+
+// Token word: id | min(index in line, 3) << 20
+#define SAGE_T_ID(w) ((w) & SAGE_ID_MASK)
+#define SAGE_T_LOC3(w) (((w) >> 20) & 3u)

@@ -1,0 +1,591 @@
+// libsage_hip.so -- host side of the C-ABI declared in include/sage_hip.h.  gfx950 (MI355X) only.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sage_hip.h"
+#include "sage_common.h"
+#include "sage_kernels.h"
+
+#define SAGE_VERSION_STR "0.1.0"
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct EventPair { hipEvent_t a, b; int cls; };
+
+}  // namespace
+
+struct sage_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // vocabulary
+    DevBuf buckets, keys, byte_id;
+    uint32_t bucket_mask = 0;
+    int max_len = 0;
+    int64_t max_id = -1;
+    bool have_vocab = false;
+
+    // corpus
+    DevBuf corpus, rem, line_off;
+    std::vector<int64_t> h_line_off;
+    int64_t n_lines = 0, nbytes = 0;
+    bool have_corpus = false;
+
+    // embeddings
+    DevBuf emb;
+    int64_t emb_rows = 0;
+    int dim = 0, dp = 0;
+    bool have_emb = false;
+
+    // scratch (grow-only; nothing is allocated in the steady state)
+    DevBuf M, ntok, tokoff, tile_sums, grand_total, tok_w0, tok_pos, set, seg_line_rel, seg_tok_off, set_base, set_mask;
+    DevBuf ex_ids, ex_starts, ex_widths;
+    DevBuf loss, occ, hist, stats, flags;
+    int64_t batch_bytes = 256ll << 20;
+    int set_factor = 16;
+
+    // measurement
+    bool profiling = false;
+    std::vector<EventPair> ev_used;
+    std::vector<hipEvent_t> ev_free;
+    double k_ms[SAGE_K_NCLASSES] = {0};
+    int64_t k_launches[SAGE_K_NCLASSES] = {0};
+    int64_t step_stats[8] = {0};
+};
+
+namespace {
+
+int fail(sage_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                                   \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+            return fail((c), SAGE_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                \
+    } while (0)
+
+int ensure(sage_ctx* c, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return SAGE_OK;
+    if (b.p) HIP_TRY(c, hipFree(b.p));
+    b.p = nullptr; b.cap = 0;
+    size_t want = bytes + bytes / 8 + 256;  // a little headroom so near-equal batches do not reallocate
+    HIP_TRY(c, hipMalloc(&b.p, want));
+    b.cap = want;
+    return SAGE_OK;
+}
+
+void release(DevBuf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr; b.cap = 0;
+}
+
+struct Prof {
+    sage_ctx* c; int cls; hipEvent_t a = nullptr, b = nullptr;
+    Prof(sage_ctx* c_, int cls_) : c(c_), cls(cls_) {
+        if (!c->profiling) return;
+        auto take = [&]() {
+            hipEvent_t e;
+            if (!c->ev_free.empty()) { e = c->ev_free.back(); c->ev_free.pop_back(); }
+            else (void)hipEventCreate(&e);
+            return e;
+        };
+        a = take(); b = take();
+        (void)hipEventRecord(a, c->stream);
+    }
+    ~Prof() {
+        if (!c->profiling) return;
+        (void)hipEventRecord(b, c->stream);
+        c->ev_used.push_back({a, b, cls});
+    }
+};
+
+void collect_events(sage_ctx* c) {
+    for (auto& e : c->ev_used) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+            c->k_ms[e.cls] += ms;
+            c->k_launches[e.cls] += 1;
+        }
+        c->ev_free.push_back(e.a);
+        c->ev_free.push_back(e.b);
+    }
+    c->ev_used.clear();
+}
+
+uint64_t pow2ceil(uint64_t x) {
+    uint64_t p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+// K1 + K2a(count) + scan over lines [line0, line1): fills M, ntok, tokoff; returns the token total.
+int match_and_count(sage_ctx* c, int64_t line0, int64_t line1, uint64_t* out_total) {
+    const int64_t pos0 = c->h_line_off[line0];
+    const uint64_t nb = (uint64_t)(c->h_line_off[line1] - pos0);
+    const uint32_t nl = (uint32_t)(line1 - line0);
+    if (nb >= 0xFFFFFF00ull) return fail(c, SAGE_E_LIMIT, "a batch must stay under 4 GiB of corpus bytes");
+    int rc;
+    if ((rc = ensure(c, c->M, std::max<uint64_t>(nb, 1) * sizeof(uint2)))) return rc;
+    if ((rc = ensure(c, c->ntok, (size_t)nl * 4))) return rc;
+    if ((rc = ensure(c, c->tokoff, ((size_t)nl + 1) * 4))) return rc;
+    const uint32_t n_tiles = cdiv(nl, SCAN_TILE);
+    if ((rc = ensure(c, c->tile_sums, (size_t)std::max(n_tiles, 1u) * 4))) return rc;
+    if ((rc = ensure(c, c->grand_total, 8))) return rc;
+
+    VocabDev v{c->buckets.as<uint4>(), c->bucket_mask, c->keys.as<uint64_t>(), c->byte_id.as<uint32_t>(), c->max_len};
+    if (nb) {
+        Prof p(c, SAGE_K_MATCH);
+        const uint32_t grid = cdiv(nb, 256);
+        const int nw = (c->max_len + 7) / 8;
+        const uint8_t* corpus = c->corpus.as<uint8_t>();
+        const uint8_t* rem = c->rem.as<uint8_t>();
+        uint2* M = c->M.as<uint2>();
+        switch (nw) {
+        case 1: k_match<1><<<grid, 256, 0, c->stream>>>(corpus, rem, pos0, (uint32_t)nb, v, M); break;
+        case 2: k_match<2><<<grid, 256, 0, c->stream>>>(corpus, rem, pos0, (uint32_t)nb, v, M); break;
+        case 3: k_match<3><<<grid, 256, 0, c->stream>>>(corpus, rem, pos0, (uint32_t)nb, v, M); break;
+        default: k_match<4><<<grid, 256, 0, c->stream>>>(corpus, rem, pos0, (uint32_t)nb, v, M); break;
+        }
+    }
+    {
+        Prof p(c, SAGE_K_WALK);
+        k_walk_count<<<cdiv(nl, 256), 256, 0, c->stream>>>(c->line_off.as<int64_t>(), line0, nl, pos0,
+                                                            c->M.as<uint2>(), c->ntok.as<uint32_t>(),
+                                                            c->flags.as<uint32_t>());
+    }
+    {
+        Prof p(c, SAGE_K_SCAN);
+        k_scan_tile_sums<<<n_tiles, 256, 0, c->stream>>>(c->ntok.as<uint32_t>(), nl, c->tile_sums.as<uint32_t>());
+        k_scan_top<<<1, 256, 0, c->stream>>>(c->tile_sums.as<uint32_t>(), n_tiles, c->grand_total.as<uint64_t>());
+        k_scan_apply<<<n_tiles, 256, 0, c->stream>>>(c->ntok.as<uint32_t>(), nl, c->tile_sums.as<uint32_t>(),
+                                                     c->tokoff.as<uint32_t>());
+    }
+    HIP_TRY(c, hipGetLastError());
+    if (out_total) {
+        uint64_t tot = 0;
+        HIP_TRY(c, hipMemcpyAsync(&tot, c->grand_total.p, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (tot >= 0xFFFFFF00ull) return fail(c, SAGE_E_LIMIT, "a batch must stay under 2^32 tokens");
+        *out_total = tot;
+    }
+    return SAGE_OK;
+}
+
+int check_ready(sage_ctx* c, bool need_emb) {
+    if (!c) return SAGE_E_ARG;
+    if (!c->have_vocab) return fail(c, SAGE_E_STATE, "sage_set_vocab has not been called");
+    if (!c->have_corpus) return fail(c, SAGE_E_STATE, "sage_set_corpus has not been called");
+    if (need_emb && !c->have_emb) return fail(c, SAGE_E_STATE, "sage_set_embeddings has not been called");
+    return SAGE_OK;
+}
+
+template <int G, int EPL>
+void launch_score(sage_ctx* c, const WalkArrays& A, uint32_t n_tok) {
+    const uint32_t gpb = 256 / G;
+    const uint32_t grid = std::min<uint32_t>(cdiv(n_tok, gpb), 256u * 16u);
+    k_score<G, EPL><<<grid, 256, 0, c->stream>>>(A, n_tok, c->emb.as<double>(), (uint32_t)c->emb_rows,
+                                                 (uint32_t)c->dp, c->loss.as<double>(), c->flags.as<uint32_t>());
+}
+
+int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, int64_t vsize, int64_t hist_len,
+              int64_t* totals /*[2] host*/) {
+    int rc;
+    if ((rc = check_ready(c, true))) return rc;
+    if (!bounds || n_seg < 0 || vsize <= 0 || hist_len < 3) return fail(c, SAGE_E_ARG, "bad argument");
+    if (pad != 2) return fail(c, SAGE_E_ARG, "only pad == 2 is implemented (model.py:138 default; utils.py:216 never overrides it)");
+    if (vsize <= c->max_id) return fail(c, SAGE_E_ARG, "vsize must exceed the largest token id");
+    for (int64_t s = 0; s < n_seg; ++s)
+        if (bounds[s] > bounds[s + 1]) return fail(c, SAGE_E_ARG, "segment bounds must be non-decreasing");
+    if (n_seg && (bounds[0] < 0 || bounds[n_seg] > c->n_lines)) return fail(c, SAGE_E_ARG, "segment bounds outside the corpus");
+    HIP_TRY(c, hipSetDevice(c->device));
+
+    if ((rc = ensure(c, c->loss, (size_t)vsize * 8))) return rc;
+    if ((rc = ensure(c, c->occ, (size_t)vsize * 8))) return rc;
+    if ((rc = ensure(c, c->hist, (size_t)hist_len * 8))) return rc;
+    if ((rc = ensure(c, c->stats, STAT_COUNT * 8))) return rc;
+
+    for (int attempt = 0;; ++attempt) {
+        HIP_TRY(c, hipMemsetAsync(c->loss.p, 0, (size_t)vsize * 8, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->occ.p, 0, (size_t)vsize * 8, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->hist.p, 0, (size_t)hist_len * 8, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->stats.p, 0, STAT_COUNT * 8, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->flags.p, 0, FLAG_COUNT * 4, c->stream));
+        uint64_t total_tokens = 0, total_bytes = 0;
+
+        int64_t sa = 0;
+        while (sa < n_seg) {
+            // a batch = as many whole segments as fit in batch_bytes (at least one)
+            int64_t sb = sa + 1;
+            while (sb < n_seg && c->h_line_off[bounds[sb + 1]] - c->h_line_off[bounds[sa]] <= c->batch_bytes) ++sb;
+            const int64_t line0 = bounds[sa], line1 = bounds[sb];
+            const uint32_t nsb = (uint32_t)(sb - sa);
+            if (line1 == line0) { sa = sb; continue; }
+            const int64_t pos0 = c->h_line_off[line0];
+            total_bytes += (uint64_t)(c->h_line_off[line1] - pos0);
+
+            if ((rc = match_and_count(c, line0, line1, nullptr))) return rc;
+
+            // token offset of every segment start
+            std::vector<uint32_t> rel(nsb + 1);
+            for (uint32_t s = 0; s <= nsb; ++s) rel[s] = (uint32_t)(bounds[sa + s] - line0);
+            if ((rc = ensure(c, c->seg_line_rel, (size_t)(nsb + 1) * 4))) return rc;
+            if ((rc = ensure(c, c->seg_tok_off, (size_t)(nsb + 1) * 4))) return rc;
+            HIP_TRY(c, hipMemcpyAsync(c->seg_line_rel.p, rel.data(), (size_t)(nsb + 1) * 4, hipMemcpyHostToDevice, c->stream));
+            k_gather_u32<<<cdiv(nsb + 1, 256), 256, 0, c->stream>>>(c->tokoff.as<uint32_t>(), c->seg_line_rel.as<uint32_t>(),
+                                                                    nsb + 1, c->seg_tok_off.as<uint32_t>());
+            std::vector<uint32_t> seg_tok(nsb + 1);
+            HIP_TRY(c, hipMemcpyAsync(seg_tok.data(), c->seg_tok_off.p, (size_t)(nsb + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            const uint32_t n_tok = seg_tok[nsb];
+            total_tokens += n_tok;
+            if (n_tok == 0) { sa = sb; continue; }
+
+            // one distinct-key set per segment
+            std::vector<uint64_t> sbase(nsb), smask(nsb);
+            uint64_t slots = 0;
+            for (uint32_t s = 0; s < nsb; ++s) {
+                const uint64_t nt = seg_tok[s + 1] - seg_tok[s];
+                const uint64_t cap = pow2ceil(std::max<uint64_t>(64, nt * (uint64_t)c->set_factor));
+                sbase[s] = slots; smask[s] = cap - 1; slots += cap;
+            }
+            if ((rc = ensure(c, c->set, slots * 8))) return rc;
+            if ((rc = ensure(c, c->set_base, (size_t)nsb * 8))) return rc;
+            if ((rc = ensure(c, c->set_mask, (size_t)nsb * 8))) return rc;
+            HIP_TRY(c, hipMemcpyAsync(c->set_base.p, sbase.data(), (size_t)nsb * 8, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(c->set_mask.p, smask.data(), (size_t)nsb * 8, hipMemcpyHostToDevice, c->stream));
+            {
+                Prof p(c, SAGE_K_MISC);
+                HIP_TRY(c, hipMemsetAsync(c->set.p, 0xFF, slots * 8, c->stream));
+            }
+            if ((rc = ensure(c, c->tok_w0, (size_t)n_tok * 4))) return rc;
+            if ((rc = ensure(c, c->tok_pos, (size_t)n_tok * 4))) return rc;
+            const uint32_t nl = (uint32_t)(line1 - line0);
+            {
+                Prof p(c, SAGE_K_WALK);
+                k_walk_write<false><<<cdiv(nl, 256), 256, 0, c->stream>>>(
+                    c->line_off.as<int64_t>(), line0, nl, pos0, c->M.as<uint2>(), c->tokoff.as<uint32_t>(),
+                    c->tok_w0.as<uint32_t>(), c->tok_pos.as<uint32_t>(), nullptr, nullptr, nullptr);
+            }
+            WalkArrays A{c->M.as<uint2>(), c->rem.as<uint8_t>() + pos0, c->tok_w0.as<uint32_t>(), c->tok_pos.as<uint32_t>()};
+            SegPlan S{c->seg_tok_off.as<uint32_t>(), c->set_base.as<uint64_t>(), c->set_mask.as<uint64_t>(), nsb};
+            {
+                Prof p(c, SAGE_K_COUNT);
+                const uint32_t grid = std::min<uint32_t>(cdiv(n_tok, 256), 256u * 16u);
+                k_ablate_count<<<grid, 256, 0, c->stream>>>(A, n_tok, S, c->set.as<unsigned long long>(),
+                                                            c->occ.as<unsigned long long>(), c->hist.as<unsigned long long>(),
+                                                            (uint32_t)hist_len, c->stats.as<unsigned long long>(),
+                                                            c->flags.as<uint32_t>());
+            }
+            {
+                Prof p(c, SAGE_K_SCORE);
+                const int dp = c->dp;
+                if (dp <= 32) launch_score<8, 4>(c, A, n_tok);
+                else if (dp <= 56) launch_score<8, 7>(c, A, n_tok);
+                else if (dp <= 64) launch_score<8, 8>(c, A, n_tok);
+                else if (dp <= 128) launch_score<16, 8>(c, A, n_tok);
+                else if (dp <= 256) launch_score<32, 8>(c, A, n_tok);
+                else if (dp <= 320) launch_score<32, 10>(c, A, n_tok);
+                else launch_score<64, 8>(c, A, n_tok);
+            }
+            HIP_TRY(c, hipGetLastError());
+            sa = sb;
+        }
+        uint32_t flags[FLAG_COUNT];
+        uint64_t stats[STAT_COUNT];
+        HIP_TRY(c, hipMemcpyAsync(flags, c->flags.p, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(stats, c->stats.p, sizeof(stats), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        collect_events(c);
+        if (flags[FLAG_EMPTY_LINE])
+            return fail(c, SAGE_E_EMPTY_LINE, "not enough values to unpack (expected 3, got 0)");
+        if (flags[FLAG_SET_OVERFLOW]) {
+            if (attempt >= 4) return fail(c, SAGE_E_LIMIT, "distinct-key set overflowed after 4 regrowths");
+            c->set_factor *= 2;  // exactness first: redo the step with larger sets
+            continue;
+        }
+        if (flags[FLAG_ROW_OOB])
+            return fail(c, SAGE_E_ROW, "a token id is out of bounds for the embedding matrix");
+        totals[0] = (int64_t)total_tokens;
+        totals[1] = (int64_t)stats[STAT_DISTINCT];
+        c->step_stats[0] = (int64_t)total_tokens;
+        c->step_stats[1] = (int64_t)total_bytes;
+        c->step_stats[2] = (int64_t)stats[STAT_OCC];
+        c->step_stats[3] = (int64_t)stats[STAT_ROWS];
+        c->step_stats[4] = (int64_t)stats[STAT_PAIRS] * 2;   // signed (t,c) records: both orders
+        c->step_stats[5] = (int64_t)stats[STAT_PAIRS];
+        return SAGE_OK;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* sage_version(void) { return SAGE_VERSION_STR; }
+
+int sage_create(int device, sage_ctx** out_ctx) {
+    if (!out_ctx) return SAGE_E_ARG;
+    *out_ctx = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return SAGE_E_HIP;
+    if (hipSetDevice(device) != hipSuccess) return SAGE_E_HIP;
+    sage_ctx* c = new sage_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SAGE_E_HIP; }
+    if (hipMalloc(&c->flags.p, FLAG_COUNT * 4) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return SAGE_E_HIP; }
+    c->flags.cap = FLAG_COUNT * 4;
+    (void)hipMemset(c->flags.p, 0, FLAG_COUNT * 4);
+    *out_ctx = c;
+    return SAGE_OK;
+}
+
+void sage_destroy(sage_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    collect_events(c);
+    for (auto e : c->ev_free) (void)hipEventDestroy(e);
+    DevBuf* all[] = {&c->buckets, &c->keys, &c->byte_id, &c->corpus, &c->rem, &c->line_off, &c->emb, &c->M, &c->ntok,
+                     &c->tokoff, &c->tile_sums, &c->grand_total, &c->tok_w0, &c->tok_pos, &c->set, &c->seg_line_rel,
+                     &c->seg_tok_off, &c->set_base, &c->set_mask, &c->ex_ids, &c->ex_starts, &c->ex_widths, &c->loss,
+                     &c->occ, &c->hist, &c->stats, &c->flags};
+    for (DevBuf* b : all) release(*b);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* sage_last_error(const sage_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int sage_set_vocab(sage_ctx* c, const uint8_t* key_bytes, const int64_t* key_offsets, const int32_t* key_ids,
+                   int64_t n_keys, int32_t max_len) {
+    if (!c || !key_bytes || !key_offsets || n_keys <= 0) return fail(c, SAGE_E_ARG, "bad argument");
+    if (max_len < 1 || max_len > SAGE_MAX_KEY_LEN) return fail(c, SAGE_E_LIMIT, "max_len must be in 1..32");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int64_t max_id = -1;
+    for (int64_t i = 0; i < n_keys; ++i) {
+        const int64_t id = key_ids ? key_ids[i] : i;
+        const int64_t len = key_offsets[i + 1] - key_offsets[i];
+        if (id < 0 || id > (int64_t)SAGE_MAX_ID) return fail(c, SAGE_E_LIMIT, "token ids must be below 2^20 - 1");
+        if (len < 1 || len > SAGE_MAX_KEY_LEN) return fail(c, SAGE_E_LIMIT, "keys must be 1..32 bytes long");
+        max_id = std::max(max_id, id);
+    }
+    std::vector<uint32_t> byte_id(256, SAGE_SLOT_EMPTY);
+    std::vector<uint64_t> keys((size_t)(max_id + 1) * 4, 0);
+    const uint64_t nbuckets = pow2ceil(std::max<uint64_t>(16, (uint64_t)n_keys / 2));  // load factor <= 0.5
+    std::vector<uint32_t> slots(nbuckets * 4, SAGE_SLOT_EMPTY);
+    const uint32_t bmask = (uint32_t)(nbuckets - 1);
+    for (int64_t i = 0; i < n_keys; ++i) {
+        const uint32_t id = (uint32_t)(key_ids ? key_ids[i] : i);
+        const uint8_t* k = key_bytes + key_offsets[i];
+        const uint32_t len = (uint32_t)(key_offsets[i + 1] - key_offsets[i]);
+        std::memcpy(reinterpret_cast<uint8_t*>(&keys[(size_t)id * 4]), k, len);
+        if (len == 1) { byte_id[k[0]] = id; continue; }  // single bytes are looked up directly
+        uint32_t h = SAGE_FNV_OFFSET;
+        for (uint32_t j = 0; j < len; ++j) h = sage_fnv_step(h, k[j]);
+        const uint32_t f = sage_mix32(h);
+        uint32_t b = f & bmask;
+        for (;;) {
+            uint32_t* s = &slots[(size_t)b * 4];
+            int q = 0;
+            while (q < 4 && s[q] != SAGE_SLOT_EMPTY) ++q;
+            if (q < 4) { s[q] = sage_slot_make(id, len, f); break; }
+            b = (b + 1) & bmask;
+        }
+    }
+    for (int b = 0; b < 256; ++b)
+        if (byte_id[b] == SAGE_SLOT_EMPTY) {
+            char msg[64];
+            std::snprintf(msg, sizeof msg, "missing byte 0x%02x", b);
+            return fail(c, SAGE_E_MISSING_BYTE, msg);
+        }
+    int rc;
+    if ((rc = ensure(c, c->buckets, slots.size() * 4))) return rc;
+    if ((rc = ensure(c, c->keys, keys.size() * 8))) return rc;
+    if ((rc = ensure(c, c->byte_id, 256 * 4))) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(c->buckets.p, slots.data(), slots.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->keys.p, keys.data(), keys.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->byte_id.p, byte_id.data(), 256 * 4, hipMemcpyHostToDevice));
+    c->bucket_mask = bmask;
+    c->max_len = max_len;
+    c->max_id = max_id;
+    c->have_vocab = true;
+    return SAGE_OK;
+}
+
+int sage_set_corpus(sage_ctx* c, const uint8_t* bytes, const int64_t* line_offsets, int64_t n_lines) {
+    if (!c || !line_offsets || n_lines < 0) return fail(c, SAGE_E_ARG, "bad argument");
+    if (line_offsets[0] != 0) return fail(c, SAGE_E_ARG, "line_offsets[0] must be 0");
+    for (int64_t i = 0; i < n_lines; ++i)
+        if (line_offsets[i + 1] < line_offsets[i]) return fail(c, SAGE_E_ARG, "line_offsets must be non-decreasing");
+    const int64_t nbytes = line_offsets[n_lines];
+    if (nbytes > 0 && !bytes) return fail(c, SAGE_E_ARG, "bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc;
+    const size_t padded = (size_t)nbytes + 1024;  // k_match stages up to 256+40 bytes past the last position
+    if ((rc = ensure(c, c->corpus, padded))) return rc;
+    if ((rc = ensure(c, c->rem, padded))) return rc;
+    if ((rc = ensure(c, c->line_off, (size_t)(n_lines + 1) * 8))) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemset(c->corpus.p, 0, padded));
+    HIP_TRY(c, hipMemset(c->rem.p, 0, padded));
+    if (nbytes) HIP_TRY(c, hipMemcpy(c->corpus.p, bytes, (size_t)nbytes, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->line_off.p, line_offsets, (size_t)(n_lines + 1) * 8, hipMemcpyHostToDevice));
+    c->h_line_off.assign(line_offsets, line_offsets + n_lines + 1);
+    c->n_lines = n_lines;
+    c->nbytes = nbytes;
+    if (nbytes) {
+        k_line_remaining<<<cdiv(nbytes, 256), 256, 0, c->stream>>>(c->line_off.as<int64_t>(), n_lines,
+                                                                   c->rem.as<uint8_t>(), nbytes);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    c->have_corpus = true;
+    return SAGE_OK;
+}
+
+int sage_set_embeddings(sage_ctx* c, const double* emb, int64_t rows, int32_t dim) {
+    if (!c || !emb || rows <= 0 || dim <= 0) return fail(c, SAGE_E_ARG, "bad argument");
+    if (dim > 512) return fail(c, SAGE_E_LIMIT, "embedding dimension above 512 is not supported");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int dp = (dim + 7) / 8 * 8;
+    int rc;
+    if ((rc = ensure(c, c->emb, (size_t)rows * dp * 8))) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (dp != dim) HIP_TRY(c, hipMemset(c->emb.p, 0, (size_t)rows * dp * 8));
+    HIP_TRY(c, hipMemcpy2D(c->emb.p, (size_t)dp * 8, emb, (size_t)dim * 8, (size_t)dim * 8, (size_t)rows, hipMemcpyHostToDevice));
+    c->emb_rows = rows;
+    c->dim = dim;
+    c->dp = dp;
+    c->have_emb = true;
+    return SAGE_OK;
+}
+
+int sage_tokenize(sage_ctx* c, int64_t line_begin, int64_t line_end, int32_t* out_ids, int32_t* out_starts,
+                  int32_t* out_widths, int64_t capacity, int64_t* out_counts, int64_t* out_total) {
+    int rc;
+    if ((rc = check_ready(c, false))) return rc;
+    if (line_begin < 0 || line_end < line_begin || line_end > c->n_lines) return fail(c, SAGE_E_ARG, "line range outside the corpus");
+    const bool want_tokens = out_ids || out_starts || out_widths;
+    if (want_tokens && !(out_ids && out_starts && out_widths)) return fail(c, SAGE_E_ARG, "pass all three token arrays or none");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemsetAsync(c->flags.p, 0, FLAG_COUNT * 4, c->stream));
+    int64_t total = 0;
+    int64_t l0 = line_begin;
+    while (l0 < line_end) {
+        int64_t l1 = l0 + 1;
+        while (l1 < line_end && c->h_line_off[l1 + 1] - c->h_line_off[l0] <= c->batch_bytes) ++l1;
+        uint64_t ntok = 0;
+        if ((rc = match_and_count(c, l0, l1, &ntok))) return rc;
+        const uint32_t nl = (uint32_t)(l1 - l0);
+        if (out_counts) {
+            std::vector<uint32_t> cnt(nl);
+            HIP_TRY(c, hipMemcpyAsync(cnt.data(), c->ntok.p, (size_t)nl * 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            for (uint32_t i = 0; i < nl; ++i) out_counts[(l0 - line_begin) + i] = cnt[i];
+        }
+        if (want_tokens && ntok) {
+            if (total + (int64_t)ntok > capacity) return fail(c, SAGE_E_ARG, "token capacity too small");
+            if ((rc = ensure(c, c->ex_ids, ntok * 4))) return rc;
+            if ((rc = ensure(c, c->ex_starts, ntok * 4))) return rc;
+            if ((rc = ensure(c, c->ex_widths, ntok * 4))) return rc;
+            {
+                Prof p(c, SAGE_K_WALK);
+                k_walk_write<true><<<cdiv(nl, 256), 256, 0, c->stream>>>(
+                    c->line_off.as<int64_t>(), l0, nl, c->h_line_off[l0], c->M.as<uint2>(), c->tokoff.as<uint32_t>(),
+                    nullptr, nullptr, c->ex_ids.as<int32_t>(), c->ex_starts.as<int32_t>(), c->ex_widths.as<int32_t>());
+            }
+            HIP_TRY(c, hipGetLastError());
+            HIP_TRY(c, hipMemcpyAsync(out_ids + total, c->ex_ids.p, ntok * 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(out_starts + total, c->ex_starts.p, ntok * 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(out_widths + total, c->ex_widths.p, ntok * 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+        total += (int64_t)ntok;
+        l0 = l1;
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    collect_events(c);
+    if (out_total) *out_total = total;
+    return SAGE_OK;
+}
+
+int sage_ablation_step(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, double* out_loss,
+                       int64_t* out_occ, int64_t vsize, int64_t* out_total_tokens, int64_t* out_total_triples,
+                       int64_t* out_hist, int64_t hist_len) {
+    if (!c) return SAGE_E_ARG;
+    if (!out_loss || !out_occ || !out_hist || !out_total_tokens || !out_total_triples) return fail(c, SAGE_E_ARG, "null output");
+    int64_t totals[2] = {0, 0};
+    int rc = step_impl(c, bounds, n_seg, pad, vsize, hist_len, totals);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpy(out_loss, c->loss.p, (size_t)vsize * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(out_occ, c->occ.p, (size_t)vsize * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(out_hist, c->hist.p, (size_t)hist_len * 8, hipMemcpyDeviceToHost));
+    *out_total_tokens = totals[0];
+    *out_total_triples = totals[1];
+    return SAGE_OK;
+}
+
+int sage_ablation_step_device(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, double* d_loss,
+                              int64_t* d_occ, int64_t vsize, int64_t* d_totals, int64_t* d_hist, int64_t hist_len) {
+    if (!c) return SAGE_E_ARG;
+    if (!d_loss || !d_occ || !d_hist || !d_totals) return fail(c, SAGE_E_ARG, "null output");
+    int64_t totals[2] = {0, 0};
+    int rc = step_impl(c, bounds, n_seg, pad, vsize, hist_len, totals);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(d_loss, c->loss.p, (size_t)vsize * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d_occ, c->occ.p, (size_t)vsize * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d_hist, c->hist.p, (size_t)hist_len * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d_totals, totals, 16, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return SAGE_OK;
+}
+
+int sage_set_profiling(sage_ctx* c, int enabled) {
+    if (!c) return SAGE_E_ARG;
+    c->profiling = enabled != 0;
+    return SAGE_OK;
+}
+
+int sage_reset_kernel_times(sage_ctx* c) {
+    if (!c) return SAGE_E_ARG;
+    for (int i = 0; i < SAGE_K_NCLASSES; ++i) { c->k_ms[i] = 0; c->k_launches[i] = 0; }
+    return SAGE_OK;
+}
+
+int sage_get_kernel_times(sage_ctx* c, double* out_ms, int64_t* out_launches) {
+    if (!c || !out_ms || !out_launches) return SAGE_E_ARG;
+    for (int i = 0; i < SAGE_K_NCLASSES; ++i) { out_ms[i] = c->k_ms[i]; out_launches[i] = c->k_launches[i]; }
+    return SAGE_OK;
+}
+
+int sage_set_batch_bytes(sage_ctx* c, int64_t bytes) {
+    if (!c || bytes < 4096) return fail(c, SAGE_E_ARG, "batch_bytes must be at least 4096");
+    c->batch_bytes = std::min<int64_t>(bytes, 0xF0000000ll);
+    return SAGE_OK;
+}
+
+int sage_get_step_stats(sage_ctx* c, int64_t* out) {
+    if (!c || !out) return SAGE_E_ARG;
+    for (int i = 0; i < 8; ++i) out[i] = c->step_stats[i];
+    return SAGE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,521 @@
+// Device kernels of libsage_hip.so -- hand-written for gfx950 (MI355X): 64-wide wavefronts, 160 KB LDS per CU,
+// HBM-bound integer/byte work plus a gather-bound f64 scoring kernel.  No MFMA on purpose: the only arithmetic
+// is a D=50 dot product per (target, context) pair.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "sage_common.h"
+
+struct VocabDev {
+    const uint4* buckets;     // nbuckets * 4 slots
+    uint32_t bucket_mask;     // nbuckets - 1
+    const uint64_t* keys;     // [id][4] zero-padded key bytes, little-endian words
+    const uint32_t* byte_id;  // id of each single-byte key
+    int max_len;
+};
+
+enum { FLAG_SET_OVERFLOW = 0, FLAG_ROW_OOB = 1, FLAG_EMPTY_LINE = 2, FLAG_COUNT = 8 };
+enum { STAT_OCC = 0, STAT_ROWS = 1, STAT_PAIRS = 2, STAT_DISTINCT = 3, STAT_COUNT = 8 };
+
+// ----------------------------------------------------------------------------------------------------------
+// rem[p] = min(255, line_end(p) - p): one byte per corpus byte, computed once per corpus (set_corpus).
+// ----------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_line_remaining(const int64_t* __restrict__ line_off, int64_t n_lines,
+                                                        uint8_t* __restrict__ rem, int64_t nbytes) {
+    int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= nbytes) return;
+    // upper_bound(line_off, p) over line_off[1..n_lines]; lanes of a wave walk nearly the same path (L1 hits)
+    int64_t lo = 0, hi = n_lines;  // find smallest l with line_off[l+1] > p
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        if (line_off[mid + 1] > p) hi = mid; else lo = mid + 1;
+    }
+    int64_t r = line_off[lo + 1] - p;
+    rem[p] = (uint8_t)(r > 255 ? 255 : r);
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// K1  match: for EVERY corpus byte p, the longest and second-longest vocabulary key that is a prefix of the
+// text at p and does not cross the line end (model.py:90-92 with the slice saturation of sent[i:i+j]).
+// One thread per byte; the block's text window is staged through LDS once; the (ML-1) candidate lengths are
+// hashed incrementally (FNV-1a), all their 16-byte bucket loads are issued before the first is consumed.
+// The table is 4 B/slot so 262,144 keys occupy 2 MiB: resident in each XCD's 4 MiB L2.
+// ----------------------------------------------------------------------------------------------------------
+template <int NW>  // key words of 8 bytes: handles max_len <= 8*NW
+__global__ __launch_bounds__(256) void k_match(const uint8_t* __restrict__ corpus, const uint8_t* __restrict__ rem,
+                                               int64_t pos0, uint32_t count, VocabDev v, uint2* __restrict__ M) {
+    constexpr int ML = 8 * NW;
+    constexpr int NDW = (256 + ML + 8) / 4 + 1;
+    __shared__ uint32_t text[NDW];
+    const uint32_t tid = threadIdx.x;
+    const int64_t blk0 = pos0 + (int64_t)blockIdx.x * 256;
+    const int64_t a0 = blk0 & ~(int64_t)3;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(corpus + a0);
+    for (uint32_t i = tid; i < NDW; i += 256) text[i] = src[i];
+    __syncthreads();
+    const uint32_t rel = blockIdx.x * 256u + tid;
+    if (rel >= count) return;
+    const uint32_t o = (uint32_t)(blk0 - a0) + tid;
+    const uint32_t wi = o >> 2, sh = (o & 3u) * 8u;
+    uint32_t T[2 * NW];
+    {
+        uint32_t d[2 * NW + 1];
+#pragma unroll
+        for (int i = 0; i <= 2 * NW; ++i) d[i] = text[wi + i];
+#pragma unroll
+        for (int i = 0; i < 2 * NW; ++i) T[i] = __funnelshift_r(d[i], d[i + 1], sh);
+    }
+    const int lim = min((int)rem[blk0 + tid], v.max_len);
+
+    // phase 1: prefix hashes, bucket loads in flight
+    uint32_t want[ML + 1];
+    uint32_t bidx[ML + 1];
+    uint4 bk[ML + 1];
+    uint32_t h = sage_fnv_step(SAGE_FNV_OFFSET, T[0] & 0xFFu);
+#pragma unroll
+    for (int j = 2; j <= ML; ++j) {
+        const uint32_t b = (T[(j - 1) >> 2] >> (8 * ((j - 1) & 3))) & 0xFFu;
+        h = sage_fnv_step(h, b);
+        const uint32_t f = sage_mix32(h);
+        want[j] = sage_slot_want(j, f);
+        bidx[j] = f & v.bucket_mask;
+        if (j <= lim) bk[j] = v.buckets[bidx[j]];
+        else bk[j] = make_uint4(SAGE_SLOT_EMPTY, SAGE_SLOT_EMPTY, SAGE_SLOT_EMPTY, SAGE_SLOT_EMPTY);
+    }
+    uint64_t W[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) W[w] = (uint64_t)T[2 * w] | ((uint64_t)T[2 * w + 1] << 32);
+
+    uint32_t id1 = v.byte_id[T[0] & 0xFFu], len1 = 1, id2 = 0, len2 = 0;
+    // phase 2: ascending lengths, so the last two hits are the longest two
+#pragma unroll
+    for (int j = 2; j <= ML; ++j) {
+        if (j > lim) continue;
+        uint4 s = bk[j];
+        uint32_t b = bidx[j];
+        bool hit = false;
+        uint32_t hid = 0;
+        for (;;) {
+            const uint32_t slot[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (!hit && slot[q] != SAGE_SLOT_EMPTY && (slot[q] >> 20) == want[j]) {
+                    const uint32_t cand = slot[q] & SAGE_ID_MASK;
+                    const uint64_t* key = v.keys + (size_t)cand * 4;
+                    bool same = true;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) {
+                        const int nb = j - 8 * w;
+                        if (nb > 0) {
+                            const uint64_t mask = nb >= 8 ? ~0ull : ((1ull << (8 * nb)) - 1ull);
+                            same = same && ((W[w] & mask) == key[w]);
+                        }
+                    }
+                    if (same) { hit = true; hid = cand; }
+                }
+            }
+            if (hit || s.w == SAGE_SLOT_EMPTY) break;
+            b = (b + 1u) & v.bucket_mask;
+            s = v.buckets[b];
+        }
+        if (hit) { id2 = id1; len2 = len1; id1 = hid; len1 = (uint32_t)j; }
+    }
+    M[rel] = make_uint2(id1 | (len1 << 20), id2 | (len2 << 20));
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// K2a  base chain: one thread per line follows p -> p + len1(p) (model.py:89-99).  Pass 1 counts tokens, pass 2
+// (after an exclusive scan of the counts) writes the compact token arrays.
+// ----------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_walk_count(const int64_t* __restrict__ line_off, int64_t line0,
+                                                    uint32_t n_lines, int64_t pos0, const uint2* __restrict__ M,
+                                                    uint32_t* __restrict__ ntok, uint32_t* __restrict__ flags) {
+    uint32_t l = blockIdx.x * 256u + threadIdx.x;
+    if (l >= n_lines) return;
+    uint32_t p = (uint32_t)(line_off[line0 + l] - pos0), e = (uint32_t)(line_off[line0 + l + 1] - pos0);
+    if (p == e) flags[FLAG_EMPTY_LINE] = 1;
+    uint32_t c = 0;
+    while (p < e) { p += SAGE_M_LEN(M[p].x); ++c; }
+    ntok[l] = c;
+}
+
+template <bool EXPORT>
+__global__ __launch_bounds__(256) void k_walk_write(const int64_t* __restrict__ line_off, int64_t line0,
+                                                    uint32_t n_lines, int64_t pos0, const uint2* __restrict__ M,
+                                                    const uint32_t* __restrict__ tok_off,
+                                                    uint32_t* __restrict__ tok_w0, uint32_t* __restrict__ tok_pos,
+                                                    int32_t* __restrict__ ex_ids, int32_t* __restrict__ ex_starts,
+                                                    int32_t* __restrict__ ex_widths) {
+    uint32_t l = blockIdx.x * 256u + threadIdx.x;
+    if (l >= n_lines) return;
+    const uint32_t p_begin = (uint32_t)(line_off[line0 + l] - pos0);
+    uint32_t p = p_begin, e = (uint32_t)(line_off[line0 + l + 1] - pos0);
+    uint32_t t = tok_off[l], c = 0;
+    while (p < e) {
+        const uint32_t m = M[p].x;
+        if (EXPORT) {
+            ex_ids[t] = (int32_t)SAGE_M_ID(m);
+            ex_starts[t] = (int32_t)(p - p_begin);
+            ex_widths[t] = (int32_t)SAGE_M_LEN(m);
+        } else {
+            tok_w0[t] = SAGE_M_ID(m) | ((c < 3u ? c : 3u) << 20);
+            tok_pos[t] = p;
+        }
+        p += SAGE_M_LEN(m);
+        ++t; ++c;
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// Exclusive scan of u32 (tokens per line -> token offset of each line), three small kernels.
+// ----------------------------------------------------------------------------------------------------------
+#define SCAN_ITEMS 8
+#define SCAN_TILE (256 * SCAN_ITEMS)
+
+__device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t* total, uint32_t* lds /*[8]*/) {
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t n = __shfl_up(incl, d, 64);
+        if (lane >= (uint32_t)d) incl += n;
+    }
+    if (lane == 63) lds[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        uint32_t s = lds[w];
+        if ((uint32_t)w < wave) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+
+__global__ __launch_bounds__(256) void k_scan_tile_sums(const uint32_t* __restrict__ in, uint32_t n,
+                                                        uint32_t* __restrict__ tile_sums) {
+    __shared__ uint32_t lds[8];
+    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) if (base + i < n) s += in[base + i];
+    uint32_t tot;
+    block_exclusive_scan_256(s, &tot, lds);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_scan_top(uint32_t* __restrict__ tile_sums, uint32_t n_tiles,
+                                                  uint64_t* __restrict__ grand_total) {
+    __shared__ uint32_t lds[8];
+    uint32_t carry = 0;
+    for (uint32_t b = 0; b < n_tiles; b += 256) {
+        const uint32_t i = b + threadIdx.x;
+        uint32_t v = i < n_tiles ? tile_sums[i] : 0u, tot;
+        uint32_t ex = block_exclusive_scan_256(v, &tot, lds);
+        if (i < n_tiles) tile_sums[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) *grand_total = carry;
+}
+
+__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__ in, uint32_t n,
+                                                    const uint32_t* __restrict__ tile_sums,
+                                                    uint32_t* __restrict__ out /* n+1 */) {
+    __shared__ uint32_t lds[8];
+    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS], s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) { v[i] = base + i < n ? in[base + i] : 0u; s += v[i]; }
+    uint32_t tot;
+    uint32_t ex = block_exclusive_scan_256(s, &tot, lds) + tile_sums[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        if (base + i < n) out[base + i] = ex;
+        ex += v[i];
+        if (base + i + 1 == n) out[n] = ex;
+    }
+}
+
+__global__ void k_gather_u32(const uint32_t* __restrict__ src, const uint32_t* __restrict__ idx, uint32_t n,
+                             uint32_t* __restrict__ dst) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// The occurrence walker: for base token t with width > 1 it generates, one element per call, first the
+// ABLATED window  [left pads] x1..xk [right pads]  and then the BASE window  [left pads] b1..bm [right pads]
+// of model.py:168-232.  Both K2b (integer counts) and K3 (f64 score) are driven by it, so the two can never
+// disagree about an occurrence.  Everything is read from the match table M, the compact token arrays and rem.
+// ----------------------------------------------------------------------------------------------------------
+struct WalkArrays {
+    const uint2* M;
+    const uint8_t* rem;       // already offset to the batch base
+    const uint32_t* tok_w0;
+    const uint32_t* tok_pos;
+};
+
+struct Walker {
+    enum State : int { A_L2, A_L1, A_X1, A_X, A_R1, A_R2, B_L2, B_L1, B_B, B_R1, B_R2, DONE };
+    int state;
+    uint32_t a, p0, q, bcur, bspan, idL1, idL2, r1, r2, k;
+    uint2 m0;
+    int pl, pr;
+    bool never;
+
+    // returns false if token t is a single byte (no ablation, model.py:170)
+    __device__ __forceinline__ bool init(const WalkArrays& A, uint32_t t) {
+        const uint32_t w0 = A.tok_w0[t];
+        k = 0;
+        p0 = A.tok_pos[t];
+        m0 = A.M[p0];
+        if (SAGE_M_LEN(m0.x) <= 1u) { state = DONE; return false; }
+        a = SAGE_T_ID(w0);
+        const uint32_t loc3 = SAGE_T_LOC3(w0);
+        pl = loc3 < 2u ? (int)loc3 : 2;                       // padleft = min(pad, loc), model.py:218
+        idL1 = pl >= 1 ? SAGE_T_ID(A.tok_w0[t - 1]) : 0u;
+        idL2 = pl >= 2 ? SAGE_T_ID(A.tok_w0[t - 2]) : 0u;
+        k = 0; pr = 0; never = false; r1 = r2 = 0; q = 0;
+        bcur = p0 + SAGE_M_LEN(m0.x);                         // start of base token loc+1 (or the line end)
+        bspan = p0;
+        state = pl == 2 ? A_L2 : (pl == 1 ? A_L1 : A_X1);
+        return true;
+    }
+    __device__ __forceinline__ int first_base_state() const { return pl == 2 ? B_L2 : (pl == 1 ? B_L1 : B_B); }
+
+    // Produces the next window element.  `fresh` = +1 / -1 when this element opens the ablated / base window.
+    // Returns false when the occurrence is finished (no element produced).
+    __device__ __forceinline__ bool next(const WalkArrays& A, uint32_t& id, bool& centre, int& fresh) {
+        fresh = 0;
+        switch (state) {
+        case A_L2: id = idL2; centre = false; fresh = +1; state = A_L1; return true;
+        case A_L1: id = idL1; centre = false; fresh = (pl == 1) ? +1 : 0; state = A_X1; return true;
+        case A_X1:  // first piece: longest key of at most width-1 bytes = second-longest match (model.py:176-182)
+            id = SAGE_M_ID(m0.y); centre = true; fresh = (pl == 0) ? +1 : 0;
+            q = p0 + SAGE_M_LEN(m0.y); k = 1; state = A_X; return true;
+        case A_X: {  // ordinary greedy steps until a base-token start or the line end (model.py:185-202)
+            const uint32_t mq = A.M[q].x;
+            const uint32_t lq = SAGE_M_LEN(mq);
+            id = SAGE_M_ID(mq); centre = true; ++k;
+            if (lq == (uint32_t)A.rem[q]) {  // reached the line end: beyond = n, no right pads (model.py:194-196)
+                never = true; pr = 0; state = first_base_state();
+            } else {
+                q += lq;
+                // advance along the base chain: is q a base-token start?  (on_base, model.py:163-165,200)
+                while (bcur < q) bcur += SAGE_M_LEN(A.M[bcur].x);
+                if (bcur == q) {
+                    const uint32_t m1 = A.M[q].x;
+                    r1 = SAGE_M_ID(m1);
+                    const uint32_t l1 = SAGE_M_LEN(m1);
+                    if (l1 == (uint32_t)A.rem[q]) pr = 1;          // padright = min(pad, ntok - beyond)
+                    else { pr = 2; r2 = SAGE_M_ID(A.M[q + l1].x); }
+                    state = A_R1;
+                }
+            }
+            return true;
+        }
+        case A_R1: id = r1; centre = false; state = pr == 2 ? A_R2 : first_base_state(); return true;
+        case A_R2: id = r2; centre = false; state = first_base_state(); return true;
+        case B_L2: id = idL2; centre = false; fresh = -1; state = B_L1; return true;
+        case B_L1: id = idL1; centre = false; fresh = (pl == 1) ? -1 : 0; state = B_B; return true;
+        case B_B: {  // base span ids[loc:beyond] (model.py:213); never-rejoined => to the end of the line
+            if (bspan == p0) fresh = (pl == 0) ? -1 : 0;
+            const uint32_t mb = A.M[bspan].x;
+            const uint32_t lb = SAGE_M_LEN(mb);
+            id = SAGE_M_ID(mb); centre = true;
+            if (never) {
+                if (lb == (uint32_t)A.rem[bspan]) state = DONE; else bspan += lb;
+            } else {
+                bspan += lb;
+                if (bspan == q) state = B_R1;
+            }
+            return true;
+        }
+        case B_R1: id = r1; centre = false; state = pr == 2 ? B_R2 : DONE; return true;
+        case B_R2: id = r2; centre = false; state = DONE; return true;
+        default: return false;
+        }
+    }
+};
+
+// ----------------------------------------------------------------------------------------------------------
+// K2b  counts: one thread per base token.  ablated_sizes histogram (model.py:208-209), occurrences per id (the
+// keys of the loss dict), and the distinct (ablated, target, context) keys per reference segment that sum to
+// total_triples (utils.py:237,245).  do_triples emits both orders of every position pair, so the set stores
+// the unordered key (a, min, max) and a new key weighs 2 (1 when target == context).
+// v1 of the distinct count: one open-addressed u64 set per segment in HBM, claimed with 64-bit CAS.
+// ----------------------------------------------------------------------------------------------------------
+struct SegPlan {
+    const uint32_t* seg_tok_off;  // [n_seg + 1] token offset of each segment inside the batch
+    const uint64_t* set_base;     // [n_seg] first slot of the segment's set
+    const uint64_t* set_mask;     // [n_seg] capacity - 1 (capacity is a power of two)
+    uint32_t n_seg;
+};
+
+__device__ __forceinline__ uint32_t find_segment(const SegPlan& S, uint32_t t) {
+    uint32_t lo = 0, hi = S.n_seg;  // largest s with seg_tok_off[s] <= t
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (S.seg_tok_off[mid] <= t) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ uint32_t set_insert(unsigned long long* __restrict__ set, uint64_t base, uint64_t mask,
+                                               uint64_t key, uint32_t* __restrict__ flags) {
+    uint64_t s = sage_mix64(key) & mask;
+    for (uint64_t probes = 0; probes <= mask; ++probes) {
+        unsigned long long* slot = set + base + s;
+        unsigned long long cur = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == key) return 0;
+        if (cur == SAGE_SET_EMPTY) {
+            cur = atomicCAS(slot, (unsigned long long)SAGE_SET_EMPTY, (unsigned long long)key);
+            if (cur == SAGE_SET_EMPTY) return 1;
+            if (cur == key) return 0;
+        }
+        s = (s + 1) & mask;
+    }
+    flags[FLAG_SET_OVERFLOW] = 1;
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void k_ablate_count(WalkArrays A, uint32_t n_tok, SegPlan S,
+                                                      unsigned long long* __restrict__ set,
+                                                      unsigned long long* __restrict__ occ,
+                                                      unsigned long long* __restrict__ hist, uint32_t hist_len,
+                                                      unsigned long long* __restrict__ stats,
+                                                      uint32_t* __restrict__ flags) {
+    __shared__ unsigned int lhist[32];
+    if (threadIdx.x < 32) lhist[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned long long n_occ = 0, n_rows = 0, n_pairs = 0, n_distinct = 0;
+    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n_tok; t += gridDim.x * 256u) {
+        Walker w;
+        if (!w.init(A, t)) continue;
+        const uint32_t seg = find_segment(S, t);
+        const uint64_t base = S.set_base[seg], mask = S.set_mask[seg];
+        const uint64_t akey = (uint64_t)w.a << 40;
+        uint32_t id, p1 = 0, p2 = 0;
+        bool c, c1 = false, c2 = false, base_window = false;
+        int have = 0, fresh;
+        while (w.next(A, id, c, fresh)) {
+            if (fresh) { have = 0; base_window = fresh < 0; }
+            if (!base_window || c) ++n_rows;  // rows touched: pads + ablated + base span (SURVEY.md 8d r-bar)
+            if (have >= 1 && (c || c1)) {
+                const uint32_t lo = min(id, p1), hi = max(id, p1);
+                const uint32_t nw = set_insert(set, base, mask, akey | ((uint64_t)lo << 20) | hi, flags);
+                n_distinct += nw ? (lo == hi ? 1u : 2u) : 0u;
+                ++n_pairs;
+            }
+            if (have >= 2 && (c || c2)) {
+                const uint32_t lo = min(id, p2), hi = max(id, p2);
+                const uint32_t nw = set_insert(set, base, mask, akey | ((uint64_t)lo << 20) | hi, flags);
+                n_distinct += nw ? (lo == hi ? 1u : 2u) : 0u;
+                ++n_pairs;
+            }
+            p2 = p1; c2 = c1; p1 = id; c1 = c; ++have;
+        }
+        ++n_occ;
+        atomicAdd(&occ[w.a], 1ull);
+        const uint32_t kk = w.k < hist_len ? w.k : hist_len - 1u;
+        if (kk < 32u) atomicAdd(&lhist[kk], 1u); else atomicAdd(&hist[kk], 1ull);
+    }
+    __syncthreads();
+    if (threadIdx.x < 32 && threadIdx.x < hist_len && lhist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)lhist[threadIdx.x]);
+    // wave-level reduction of the statistics, one atomic per wave
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        n_occ += __shfl_down(n_occ, d, 64);
+        n_rows += __shfl_down(n_rows, d, 64);
+        n_pairs += __shfl_down(n_pairs, d, 64);
+        n_distinct += __shfl_down(n_distinct, d, 64);
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        if (n_occ) atomicAdd(&stats[STAT_OCC], n_occ);
+        if (n_rows) atomicAdd(&stats[STAT_ROWS], n_rows);
+        if (n_pairs) atomicAdd(&stats[STAT_PAIRS], n_pairs);
+        if (n_distinct) atomicAdd(&stats[STAT_DISTINCT], n_distinct);
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// K3  score: loss[a] -= sign * count * log(sigmoid(E[t].E[c]))  (utils.py:125-138,255) evaluated directly per
+// occurrence in float64.  G lanes own one occurrence; a lane holds EPL elements of each of the last three
+// window rows, so every embedding row is fetched once per window as one coalesced segment.  The dot of a pair is
+// reduced across the G lanes; the G lanes then each take ONE of the pending dots through log-sigmoid, so the
+// transcendental work is not replicated.  Each position pair stands for both (t,c) orders: weight 2.
+// ----------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double log_sigmoid(double x) {
+    // log(expit(x)) of utils.py:136 in its overflow-free form; equal to 1 ulp for |x| < 700
+    return fmin(x, 0.0) - log1p(exp(-fabs(x)));
+}
+
+template <int G, int EPL>
+__global__ __launch_bounds__(256) void k_score(WalkArrays A, uint32_t n_tok, const double* __restrict__ emb,
+                                               uint32_t emb_rows, uint32_t dp, double* __restrict__ loss,
+                                               uint32_t* __restrict__ flags) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t gl = lane % G;                       // lane inside the group
+    const uint32_t groups_per_block = 256 / G;
+    const uint32_t group0 = blockIdx.x * groups_per_block + threadIdx.x / G;
+    const uint32_t group_stride = gridDim.x * groups_per_block;
+
+    for (uint32_t t0 = blockIdx.x * groups_per_block; t0 < n_tok; t0 += group_stride) {
+        const uint32_t t = t0 + threadIdx.x / G;
+        (void)group0;
+        Walker w;
+        bool active = t < n_tok && w.init(A, t);
+        double r0[EPL], r1[EPL], r2[EPL];
+        bool c1 = false, c2 = false;
+        int have = 0;
+        double sign = 1.0, acc = 0.0, pend_val = 0.0, pend_sgn = 0.0;
+        int pend = 0;
+        while (__any(active)) {
+            if (active) {
+                uint32_t id; bool c; int fresh;
+                if (w.next(A, id, c, fresh)) {
+                    if (fresh) { have = 0; sign = fresh > 0 ? 1.0 : -1.0; }
+                    if (id >= emb_rows) { flags[FLAG_ROW_OOB] = 1; id = 0; }
+                    const double* row = emb + (size_t)id * dp;
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) {
+                        const uint32_t idx = gl + (uint32_t)G * e;
+                        r0[e] = idx < dp ? row[idx] : 0.0;
+                    }
+                    if (have >= 1 && (c || c1)) {
+                        double d = 0.0;
+#pragma unroll
+                        for (int e = 0; e < EPL; ++e) d = fma(r0[e], r1[e], d);
+#pragma unroll
+                        for (int m = G / 2; m >= 1; m >>= 1) d += __shfl_xor(d, m, G);
+                        if ((int)gl == pend) { pend_val = d; pend_sgn = sign; }
+                        ++pend;
+                    }
+                    if (have >= 2 && (c || c2)) {
+                        double d = 0.0;
+#pragma unroll
+                        for (int e = 0; e < EPL; ++e) d = fma(r0[e], r2[e], d);
+#pragma unroll
+                        for (int m = G / 2; m >= 1; m >>= 1) d += __shfl_xor(d, m, G);
+                        if ((int)gl == pend) { pend_val = d; pend_sgn = sign; }
+                        ++pend;
+                    }
+#pragma unroll
+                    for (int e = 0; e < EPL; ++e) { r2[e] = r1[e]; r1[e] = r0[e]; }
+                    c2 = c1; c1 = c; ++have;
+                } else {
+                    active = false;
+                }
+            }
+            // wave-synchronous flush: one log-sigmoid per lane covers G pending pairs of its group
+            if (__any(pend > G - 2) || !__any(active)) {
+                if ((int)gl < pend) acc += pend_sgn * log_sigmoid(pend_val);
+                pend = 0;
+            }
+        }
+#pragma unroll
+        for (int m = G / 2; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, G);
+        if (gl == 0 && t < n_tok && w.k > 0) unsafeAtomicAdd(&loss[w.a], -2.0 * acc);
+    }
+}

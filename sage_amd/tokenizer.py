@@ -1,0 +1,99 @@
+"""SaGeTokenizer: the reference's tokenizer API (model.py:13-255) with the work done by the HIP library.
+
+State (the four dicts) lives on the host exactly as in the reference, because SaGeVocabBuilder and the file
+writers read it (SaGeVocabBuilder.py:57,68,83,109,159,166-192).  Matching itself -- `tokenize` and everything
+built on it -- runs on the GPU through libsage_hip.so; there is no CPU matcher in this package.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence, Tuple, Union
+
+import numpy as np
+
+from .hf_bytes import HFEncoding
+
+Tokenizable = Union[str, bytes]
+
+
+def require_all_single_bytes(vocab: Dict[bytes, int]) -> None:
+    """model.py:251-255."""
+    for b in range(256):
+        key = bytes([b])
+        if key not in vocab:
+            raise Exception(f"missing byte {key}")
+
+
+class SaGeTokenizer:
+    def __init__(self, initial_vocabulary: Sequence[bytes], max_len: int = 16):
+        self.hfe = HFEncoding()
+        self.byte_vocab: Dict[bytes, int] = None
+        self.inv_byte_vocab: Dict[int, bytes] = None
+        self.str_vocab: Dict[str, int] = None
+        self.inv_str_vocab: Dict[int, str] = None
+        self.vocab_version = 0      # bumped on every set_vocabulary; engines re-upload when it changes
+        self.max_len = max_len
+        self.set_vocabulary(initial_vocabulary)
+
+    # ---- vocabulary state (model.py:28-79) ----------------------------------------------------------------
+    @staticmethod
+    def set_bytes_vocab(new_vocab: Sequence[bytes]) -> Dict[bytes, int]:
+        table: Dict[bytes, int] = {}
+        for position, key in enumerate(new_vocab):
+            assert type(key) == bytes
+            table[key] = position           # a repeated key keeps its last position, as a dict does
+        return table
+
+    def set_vocabulary(self, new_vocab: Sequence[bytes]) -> None:
+        table = self.set_bytes_vocab(new_vocab)
+        require_all_single_bytes(table)
+        self.byte_vocab = table
+        self.inv_byte_vocab = {i: k for k, i in table.items()}
+        enc = self.hfe.to_encoded
+        self.str_vocab = {enc(k): i for k, i in table.items()}
+        self.inv_str_vocab = {i: s for s, i in self.str_vocab.items()}
+        self.vocab_version += 1
+
+    def id_to_bytes(self, token_id: int) -> bytes:
+        return self.inv_byte_vocab[token_id]
+
+    def id_to_encoded(self, token_id: int) -> str:
+        return self.inv_str_vocab[token_id]
+
+    def get_vocabulary(self) -> Dict[bytes, int]:
+        return self.byte_vocab
+
+    def vocab_size(self) -> int:
+        return len(self.byte_vocab)
+
+    def print_tokens(self, ids: List[int]) -> List[bytes]:
+        return [self.inv_byte_vocab[i] for i in ids]
+
+    def add_all_byte_ids(self, vocab: Dict[int, float], score: float = 1e400) -> None:
+        for b in range(256):
+            vocab[self.byte_vocab[bytes([b])]] = score
+
+    # ---- matching, on the GPU (model.py:81-113) -----------------------------------------------------------
+    def tokenize_lines(self, lines: Sequence[Tokenizable]):
+        """Batch form of `tokenize`: -> (ids, starts, widths int32 arrays back to back, counts per line)."""
+        from . import parallel
+        return parallel.tokenize_lines(self, lines)
+
+    def tokenize(self, sent: Tokenizable, tokens_only: bool = False):
+        ids, starts, widths, _ = self.tokenize_lines([sent])
+        if tokens_only:
+            return ids.tolist()
+        return list(zip(ids.tolist(), starts.tolist(), widths.tolist()))
+
+    def tokenize_to_encoded_str(self, sent: Tokenizable) -> List[str]:
+        inv = self.inv_str_vocab
+        return [inv[i] for i in self.tokenize(sent, tokens_only=True)]
+
+    def tokenize_to_bytes(self, sent: Tokenizable) -> List[bytes]:
+        inv = self.inv_byte_vocab
+        return [inv[i] for i in self.tokenize(sent, tokens_only=True)]
+
+    # ---- what the engine uploads --------------------------------------------------------------------------
+    def key_table(self) -> Tuple[List[bytes], np.ndarray]:
+        keys = list(self.byte_vocab.keys())
+        ids = np.fromiter(self.byte_vocab.values(), dtype=np.int32, count=len(keys))
+        return keys, ids

@@ -1,0 +1,161 @@
+"""GPU parity: the HIP path (through the C-ABI) against the golden vectors of the reference and against the
+oracle on seeded inputs.  Integers bit-exact; per-token losses within 1e-5 relative (north star) -- the absolute
+floor of 1e-9 * sum|terms| covers ids whose loss is a near-total cancellation."""
+import numpy as np
+import pytest
+
+from tests.golden_io import load_json_gz, load_npz, unpack
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+def _engine():
+    from sage_amd._lib import HipSage
+    return HipSage(0)
+
+
+def _pack(lines):
+    from sage_amd.parallel import pack_lines
+    return pack_lines(lines)
+
+
+@pytest.mark.parametrize("tag", ["en16", "tr17"])
+def test_tokenize_golden(tag):
+    g = load_npz(f"tokenize_{tag}.npz")
+    vocab = unpack(g["vocab_bytes"], g["vocab_off"])
+    lines = unpack(g["line_bytes"], g["line_off"])
+    eng = _engine()
+    eng.set_vocab(vocab, None, int(g["max_len"]))
+    eng.set_corpus(g["line_bytes"], g["line_off"])
+    ids, starts, widths, counts = eng.tokenize(0, len(lines))
+    assert counts.tolist() == g["counts"].tolist()
+    assert ids.tolist() == g["ids"].tolist()
+    assert starts.tolist() == g["starts"].tolist()
+    assert widths.tolist() == g["widths"].tolist()
+    # small batches must give the same answer (batch seams)
+    eng.set_batch_bytes(4096)
+    ids2, starts2, widths2, counts2 = eng.tokenize(0, len(lines))
+    assert ids2.tolist() == ids.tolist() and starts2.tolist() == starts.tolist()
+    assert widths2.tolist() == widths.tolist() and counts2.tolist() == counts.tolist()
+    eng.close()
+
+
+def _check_step(eng, bounds, want_tokens, want_triples, want_losses, want_sizes, want_occ=None, abs_scale=None):
+    loss, occ, tt, ttr, hist = eng.ablation_step(bounds)
+    assert tt == want_tokens
+    assert ttr == want_triples
+    ids = np.nonzero(occ)[0]
+    assert ids.tolist() == sorted(want_losses.keys())
+    if want_occ is not None:
+        assert {int(i): int(occ[i]) for i in ids} == want_occ
+    got = loss[ids]
+    want = np.array([want_losses[int(i)] for i in ids])
+    atol = 1e-9 * (abs_scale if abs_scale is not None else max(1.0, float(np.abs(want).max())))
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=atol)
+    ks = np.nonzero(hist)[0]
+    assert {int(k): int(hist[k]) for k in ks} == {int(k): int(v) for k, v in want_sizes.items()}
+
+
+@pytest.mark.parametrize("workers", [1, 3, 4])
+def test_run_sage_parallel_golden(workers):
+    """20,600 lines: pins flush rule (10,001 / 10,000), shard sizes, total_triples, negation."""
+    from sage_amd import synth
+    from sage_amd.parallel import segment_line_bounds
+    g = load_npz("parallel.npz")
+    vocab = unpack(g["vocab_bytes"], g["vocab_off"])
+    emb = synth.make_embeddings(len(vocab), int(g["emb_dim"]), seed=int(g["emb_seed"]))
+    assert float(emb.sum()) == float(g["emb_checksum"])
+    eng = _engine()
+    eng.set_vocab(vocab, None, int(g["max_len"]))
+    eng.set_corpus(g["line_bytes"], g["line_off"])
+    eng.set_embeddings(emb)
+    n_lines = len(g["line_off"]) - 1
+    W = workers
+    want_losses = dict(zip(g[f"w{W}_loss_ids"].tolist(), g[f"w{W}_loss_vals"].tolist()))
+    want_sizes = dict(zip(g[f"w{W}_size_keys"].tolist(), g[f"w{W}_size_vals"].tolist()))
+    _check_step(eng, segment_line_bounds(n_lines, W), int(g[f"w{W}_total_tokens"]), int(g[f"w{W}_total_triples"]),
+                want_losses, want_sizes)
+    # the same step in many small batches
+    eng.set_batch_bytes(64 * 1024)
+    _check_step(eng, segment_line_bounds(n_lines, W), int(g[f"w{W}_total_tokens"]), int(g[f"w{W}_total_triples"]),
+                want_losses, want_sizes)
+    eng.close()
+
+
+@pytest.mark.parametrize("cs", [7, 20, 60])
+def test_small_flush_golden(cs):
+    from sage_amd import synth
+    from sage_amd.parallel import segment_line_bounds
+    g = load_npz("parallel.npz")
+    vocab = unpack(g["vocab_bytes"], g["vocab_off"])
+    emb = synth.make_embeddings(len(vocab), int(g["emb_dim"]), seed=int(g["emb_seed"]))
+    eng = _engine()
+    eng.set_vocab(vocab, None, int(g["max_len"]))
+    off = g["line_off"][:62]
+    eng.set_corpus(g["line_bytes"][:off[-1]], off)
+    eng.set_embeddings(emb)
+    loss, occ, tt, ttr, hist = eng.ablation_step(segment_line_bounds(61, 1, flush=cs))
+    assert tt == int(g[f"chunk{cs}_total_tokens"])
+    assert ttr == int(g[f"chunk{cs}_total_triples"])
+    ids = np.nonzero(occ)[0]
+    assert ids.tolist() == g[f"chunk{cs}_loss_ids"].tolist()
+    np.testing.assert_allclose(loss[ids], g[f"chunk{cs}_loss_vals"], rtol=RTOL, atol=1e-9)
+    eng.close()
+
+
+@pytest.mark.parametrize("tag", ["en16", "tr17"])
+def test_fast_sage_lines_golden(tag):
+    """Per line: the distinct-key count and the ablated-size histogram of the reference's fast_sage."""
+    g = load_json_gz(f"fast_sage_{tag}.json.gz")
+    vocab = [bytes.fromhex(h) for h in g["vocab"]]
+    cases = [c for c in g["cases"] if c["pad"] == 2]
+    lines = [bytes.fromhex(c["line"]) for c in cases]
+    from sage_amd import synth
+    eng = _engine()
+    eng.set_vocab(vocab, None, g["max_len"])
+    flat, off = _pack(lines)
+    eng.set_corpus(flat, off)
+    eng.set_embeddings(synth.make_embeddings(len(vocab), 50, seed=1))
+    for i, case in enumerate(cases):
+        loss, occ, tt, ttr, hist = eng.ablation_step(np.array([i, i + 1]))
+        assert tt == case["ret"]
+        assert ttr == len(case["keys"]), (i, case["line"])
+        ks = np.nonzero(hist)[0]
+        assert {str(int(k)): int(hist[k]) for k in ks} == case["sizes"]
+        want_occ = {}
+        for (a, _, _) in case["keys"]:
+            want_occ[a] = 1
+        assert sorted(np.nonzero(occ)[0].tolist()) == sorted(want_occ)
+    eng.close()
+
+
+@pytest.mark.parametrize("style,max_len,dim", [("en", 16, 50), ("tr", 17, 50), ("en", 16, 300), ("en", 24, 20)])
+def test_step_vs_oracle(style, max_len, dim):
+    from oracle import sage_oracle as orc
+    from sage_amd import synth
+    from sage_amd.parallel import segment_line_bounds
+    corpus, off = synth.make_corpus(400, seed=11 + max_len + dim, style=style, n_types=2500, mean_log_words=2.8)
+    vocab = synth.make_vocab(corpus, off, 3000, max_len, sample_bytes=300_000)
+    emb = synth.make_embeddings(len(vocab), dim, seed=5)
+    lines = synth.corpus_lines(corpus, off)
+    tok = orc.OracleTokenizer(vocab, max_len)
+    occs = {}
+    want = None
+    for W, flush in ((2, 97),):
+        losses, sizes, tt, ttr = {}, {}, 0, 0
+        for lo, hi in orc.shard_bounds(len(lines), W):
+            l, t, r, s = orc.run_shard(tok, lines[lo:hi], emb, flush=flush, occurrences=occs)
+            tt += t; ttr += r
+            for k, v in l.items():
+                losses[k] = losses.get(k, 0) + v
+            for k, v in s.items():
+                sizes[k] = sizes.get(k, 0) + v
+        want = (tt, ttr, losses, sizes)
+        eng = _engine()
+        eng.set_vocab(vocab, None, max_len)
+        eng.set_corpus(corpus, off)
+        eng.set_embeddings(emb)
+        _check_step(eng, segment_line_bounds(len(lines), W, flush=flush), tt, ttr, losses, sizes, want_occ=occs)
+        eng.close()
