@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- one ablation step of SaGe 2.0 on MI355X (BASELINE.json metric / configs[1]).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (greedy tokenization + ablation counts + f64 scoring, i.e. one
+run_sage_parallel call, utils.py:141-257) over the rank's resident corpus shard.  Workload at N=1: the 1M-line
+synthetic English-Wikipedia-shaped corpus with a 262,144-key vocabulary (BASELINE.json configs[1]); at N>1 every
+rank holds its own 1M-line shard (weak scaling) and the per-step result vectors (loss f64[V], occurrences
+i64[V], histogram, totals) are combined over RCCL.  Corpus, vocabulary and embeddings are uploaded before the
+timed region; the timed region is K steps between barrier + synchronize pairs; rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--lines", type=int, default=1_000_000, help="lines per GPU")
+    ap.add_argument("--vocab", type=int, default=262_144)
+    ap.add_argument("--dim", type=int, default=50)
+    ap.add_argument("--max-len", type=int, default=16)
+    ap.add_argument("--workers", type=int, default=4, help="reference workers_number (defines count segments; run.sh uses 4)")
+    ap.add_argument("--style", default="en")
+    ap.add_argument("--cpu-lines", type=int, default=0, help="lines of the CPU-baseline sample (0 = auto, <0 = skip)")
+    ap.add_argument("--batch-mb", type=int, default=0)
+    return ap.parse_args()
+
+
+def cpu_baseline(corpus, offsets, vocab, max_len, emb, n_lines_req):
+    """The oracle (a dict-based port of the reference algorithm, like the reference one process per shard) timed on
+    this host: kind "port".  Bounded sample of the same corpus so the default run stays within minutes."""
+    from oracle import sage_oracle as orc
+    from sage_amd import synth
+    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or (os.cpu_count() or 1))
+    cores = max(1, min(cores, 32))
+    n = n_lines_req if n_lines_req > 0 else cores * 160
+    n = min(n, len(offsets) - 1)
+    sub_off = offsets[:n + 1]
+    lines = synth.corpus_lines(corpus[:sub_off[-1]], sub_off)
+    tok = orc.OracleTokenizer(vocab, max_len)
+    t0 = time.time()
+    tt, ttr, losses, sizes = orc.run_parallel(emb, lines, tok, cores, processes=cores)
+    dt = time.time() - t0
+    return {"value": tt / dt, "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"first {n} lines ({tt} tokens) of the same corpus, oracle/sage_oracle.py run_parallel with "
+                      f"{cores} worker processes (pool start + pickling of vocab/embeddings included, as in the reference), {dt:.1f} s"}
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from sage_amd import synth
+    from sage_amd._lib import HipSage
+    from sage_amd.parallel import segment_line_bounds
+
+    seed = synth.DEFAULT_SEED
+    t_gen = time.time()
+    # the vocabulary comes from the head of shard 0 so that every rank builds the same one
+    n_types = 1_000_000 if args.lines > 200_000 else 50_000
+    head_lines = min(args.lines, 14_000)
+    log(f"rank {rank}/{world}: generating vocabulary sample")
+    head, head_off = synth.make_corpus(head_lines, seed=seed, style=args.style, n_types=n_types)
+    vocab = synth.make_vocab(head, head_off, args.vocab, args.max_len, sample_bytes=6_000_000)
+    if rank == 0 and args.lines == head_lines:
+        corpus, offsets = head, head_off
+    else:
+        log(f"vocabulary of {len(vocab)} keys built; generating {args.lines} lines")
+        corpus, offsets = synth.make_corpus(args.lines, seed=seed + rank, style=args.style, n_types=n_types,
+                                            progress=log)
+    log(f"corpus: {len(corpus)} bytes")
+    emb = synth.make_embeddings(len(vocab), args.dim, seed=seed)
+    gen_s = time.time() - t_gen
+
+    eng = HipSage(local_rank)
+    if args.batch_mb:
+        eng.set_batch_bytes(args.batch_mb << 20)
+    t_up = time.time()
+    eng.set_vocab(vocab, None, args.max_len)
+    eng.set_corpus(corpus, offsets)
+    eng.set_embeddings(emb)
+    upload_s = time.time() - t_up
+    log(f"uploaded in {upload_s:.1f} s")
+    bounds = segment_line_bounds(len(offsets) - 1, args.workers)
+    V = len(vocab)
+    H = HipSage.HIST_LEN
+    d_loss = torch.zeros(V, dtype=torch.float64, device="cuda")
+    d_occ = torch.zeros(V, dtype=torch.int64, device="cuda")
+    d_hist = torch.zeros(H, dtype=torch.int64, device="cuda")
+    d_tot = torch.zeros(2, dtype=torch.int64, device="cuda")
+
+    def step():
+        eng.ablation_step_device(bounds, (d_loss.data_ptr(), V), d_occ.data_ptr(), d_tot.data_ptr(), (d_hist.data_ptr(), H))
+        if world > 1:
+            from sage_amd.dist import combine_device
+            combine_device(dist, d_loss, d_occ, d_hist, d_tot)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+        log("warmup step done")
+    eng.set_profiling(True)
+    eng.reset_kernel_times()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    eng.set_profiling(False)
+    log(f"{args.steps} timed steps: {dt:.3f} s")
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    total_tokens = int(d_tot[0].item())      # whole job (already combined over ranks)
+    total_triples = int(d_tot[1].item())
+    ms_per_step = dt / args.steps * 1e3
+
+    if rank == 0:
+        st = eng.step_stats()                 # this rank's shard
+        kt = eng.kernel_times()
+        # ---- algorithmic bytes, statistics measured on this very corpus ----
+        tokens_local = st["tokens"]
+        b_bar = st["corpus_bytes"] / tokens_local
+        f_m = st["occurrences"] / tokens_local
+        r_bar = st["rows"] / max(1, st["occurrences"])
+        p_bar = st["records"] / max(1, st["occurrences"])
+        A = b_bar + 9 + f_m * (r_bar * args.dim * 8 + 16 * p_bar)
+        per_kernel_bytes = {   # per step, this rank; DESIGN.md "Kernels" states each figure
+            "match": st["corpus_bytes"] * (1 + 1 + 8),
+            "walk": st["corpus_bytes"] * 8 / max(1.0, b_bar) * 2 + tokens_local * 8,
+            "count": st["records"] * 8 * 2,
+            "score": st["rows"] * args.dim * 8,
+        }
+        dom = max(("match", "walk", "count", "score"), key=lambda k: kt[k][0])
+        dom_ms, dom_n = kt[dom]
+        launches_per_step = max(1, dom_n // args.steps)
+        avg_ms = dom_ms / max(1, dom_n)
+        achieved = per_kernel_bytes[dom] / launches_per_step / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        step_gbs = A * total_tokens / (dt / args.steps) / 1e9 / world
+        out = {
+            "metric": "corpus tokens scored/sec per ablation step (node) @262k vocab + HBM GB/s",
+            "value": total_tokens * args.steps / dt,
+            "unit": "tokens/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{args.lines}-line synthetic {args.style}-wiki-shaped corpus per GPU, single "
+                                   f"{args.vocab}-key vocabulary ablation step (tokenize + score + counts), D={args.dim}, "
+                                   f"max_len={args.max_len}, pad=2, workers_number={args.workers}",
+                       "lines_per_gpu": args.lines, "vocab": len(vocab), "dim": args.dim, "max_len": args.max_len,
+                       "corpus_bytes_per_gpu": int(st["corpus_bytes"]), "total_tokens": total_tokens,
+                       "total_triples": total_triples},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step,
+                         "algorithmic_bytes_per_launch": per_kernel_bytes[dom] / launches_per_step},
+            "step_roofline": {"bytes_per_token_A": A, "achieved_GBs_per_gpu": step_gbs, "frac": step_gbs / HBM_PEAK_GBS,
+                              "b_bar": b_bar, "f_m": f_m, "r_bar": r_bar, "p_bar": p_bar},
+            "kernel_ms_per_step": {k: kt[k][0] / args.steps for k in kt},
+            "setup_s": {"generate": gen_s, "upload": upload_s},
+        }
+        if args.cpu_lines >= 0 and world == 1:
+            out["cpu_baseline"] = cpu_baseline(corpus, offsets, vocab, args.max_len, emb, args.cpu_lines)
+        elif world == 1:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

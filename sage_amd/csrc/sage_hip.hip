@@ -50,7 +50,7 @@ struct sage_ctx {
     bool have_emb = false;
 
     // scratch (grow-only; nothing is allocated in the steady state)
-    DevBuf M, ntok, tokoff, tile_sums, grand_total, tok_w0, tok_pos, set, seg_line_rel, seg_tok_off, set_base, set_mask;
+    DevBuf M, ntok, tokoff, tile_sums, grand_total, tok_w0, tok_pos, set, seg_line_rel, seg_tok_off, set_base, set_mask, seg_pairs;
     DevBuf ex_ids, ex_starts, ex_widths;
     DevBuf loss, occ, hist, stats, flags;
     int64_t batch_bytes = 256ll << 20;
@@ -257,23 +257,6 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
             total_tokens += n_tok;
             if (n_tok == 0) { sa = sb; continue; }
 
-            // one distinct-key set per segment
-            std::vector<uint64_t> sbase(nsb), smask(nsb);
-            uint64_t slots = 0;
-            for (uint32_t s = 0; s < nsb; ++s) {
-                const uint64_t nt = seg_tok[s + 1] - seg_tok[s];
-                const uint64_t cap = pow2ceil(std::max<uint64_t>(64, nt * (uint64_t)c->set_factor));
-                sbase[s] = slots; smask[s] = cap - 1; slots += cap;
-            }
-            if ((rc = ensure(c, c->set, slots * 8))) return rc;
-            if ((rc = ensure(c, c->set_base, (size_t)nsb * 8))) return rc;
-            if ((rc = ensure(c, c->set_mask, (size_t)nsb * 8))) return rc;
-            HIP_TRY(c, hipMemcpyAsync(c->set_base.p, sbase.data(), (size_t)nsb * 8, hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(c, hipMemcpyAsync(c->set_mask.p, smask.data(), (size_t)nsb * 8, hipMemcpyHostToDevice, c->stream));
-            {
-                Prof p(c, SAGE_K_MISC);
-                HIP_TRY(c, hipMemsetAsync(c->set.p, 0xFF, slots * 8, c->stream));
-            }
             if ((rc = ensure(c, c->tok_w0, (size_t)n_tok * 4))) return rc;
             if ((rc = ensure(c, c->tok_pos, (size_t)n_tok * 4))) return rc;
             const uint32_t nl = (uint32_t)(line1 - line0);
@@ -284,14 +267,40 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
                     c->tok_w0.as<uint32_t>(), c->tok_pos.as<uint32_t>(), nullptr, nullptr, nullptr);
             }
             WalkArrays A{c->M.as<uint2>(), c->rem.as<uint8_t>() + pos0, c->tok_w0.as<uint32_t>(), c->tok_pos.as<uint32_t>()};
+            if ((rc = ensure(c, c->set_base, (size_t)nsb * 8))) return rc;
+            if ((rc = ensure(c, c->set_mask, (size_t)nsb * 8))) return rc;
+            if ((rc = ensure(c, c->seg_pairs, (size_t)nsb * 8))) return rc;
+            HIP_TRY(c, hipMemsetAsync(c->seg_pairs.p, 0, (size_t)nsb * 8, c->stream));
             SegPlan S{c->seg_tok_off.as<uint32_t>(), c->set_base.as<uint64_t>(), c->set_mask.as<uint64_t>(), nsb};
+            const uint32_t cgrid = std::min<uint32_t>(cdiv(n_tok, 256), 256u * 16u);
             {
                 Prof p(c, SAGE_K_COUNT);
-                const uint32_t grid = std::min<uint32_t>(cdiv(n_tok, 256), 256u * 16u);
-                k_ablate_count<<<grid, 256, 0, c->stream>>>(A, n_tok, S, c->set.as<unsigned long long>(),
-                                                            c->occ.as<unsigned long long>(), c->hist.as<unsigned long long>(),
-                                                            (uint32_t)hist_len, c->stats.as<unsigned long long>(),
-                                                            c->flags.as<uint32_t>());
+                k_ablate_count<false><<<cgrid, 256, 0, c->stream>>>(
+                    A, n_tok, S, nullptr, c->seg_pairs.as<unsigned long long>(), c->occ.as<unsigned long long>(),
+                    c->hist.as<unsigned long long>(), (uint32_t)hist_len, c->stats.as<unsigned long long>(),
+                    c->flags.as<uint32_t>());
+            }
+            // one distinct-key set per segment, sized from the exact pair count: load factor <= 0.5
+            std::vector<uint64_t> sbase(nsb), smask(nsb), spairs(nsb);
+            HIP_TRY(c, hipMemcpyAsync(spairs.data(), c->seg_pairs.p, (size_t)nsb * 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            uint64_t slots = 0;
+            for (uint32_t s = 0; s < nsb; ++s) {
+                const uint64_t cap = pow2ceil(std::max<uint64_t>(64, spairs[s] * 2));
+                sbase[s] = slots; smask[s] = cap - 1; slots += cap;
+            }
+            if ((rc = ensure(c, c->set, slots * 8))) return rc;
+            HIP_TRY(c, hipMemcpyAsync(c->set_base.p, sbase.data(), (size_t)nsb * 8, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(c->set_mask.p, smask.data(), (size_t)nsb * 8, hipMemcpyHostToDevice, c->stream));
+            {
+                Prof p(c, SAGE_K_MISC);
+                HIP_TRY(c, hipMemsetAsync(c->set.p, 0xFF, slots * 8, c->stream));
+            }
+            {
+                Prof p(c, SAGE_K_COUNT);
+                k_ablate_count<true><<<cgrid, 256, 0, c->stream>>>(
+                    A, n_tok, S, c->set.as<unsigned long long>(), nullptr, nullptr, nullptr, (uint32_t)hist_len,
+                    c->stats.as<unsigned long long>(), c->flags.as<uint32_t>());
             }
             {
                 Prof p(c, SAGE_K_SCORE);
@@ -364,7 +373,7 @@ void sage_destroy(sage_ctx* c) {
     for (auto e : c->ev_free) (void)hipEventDestroy(e);
     DevBuf* all[] = {&c->buckets, &c->keys, &c->byte_id, &c->corpus, &c->rem, &c->line_off, &c->emb, &c->M, &c->ntok,
                      &c->tokoff, &c->tile_sums, &c->grand_total, &c->tok_w0, &c->tok_pos, &c->set, &c->seg_line_rel,
-                     &c->seg_tok_off, &c->set_base, &c->set_mask, &c->ex_ids, &c->ex_starts, &c->ex_widths, &c->loss,
+                     &c->seg_tok_off, &c->set_base, &c->set_mask, &c->seg_pairs, &c->ex_ids, &c->ex_starts, &c->ex_widths, &c->loss,
                      &c->occ, &c->hist, &c->stats, &c->flags};
     for (DevBuf* b : all) release(*b);
     (void)hipStreamDestroy(c->stream);

@@ -380,49 +380,82 @@ __device__ __forceinline__ uint32_t set_insert(unsigned long long* __restrict__ 
     return 0;
 }
 
+// Pass 0 (INSERT=false): histogram, occurrences and the number of position pairs of every segment (which sizes
+// that segment's set at load <= 0.5, so pass 1 can neither overflow nor degrade).  Pass 1 (INSERT=true): the
+// same walk inserting the keys.
+template <bool INSERT>
 __global__ __launch_bounds__(256) void k_ablate_count(WalkArrays A, uint32_t n_tok, SegPlan S,
                                                       unsigned long long* __restrict__ set,
+                                                      unsigned long long* __restrict__ seg_pairs,
                                                       unsigned long long* __restrict__ occ,
                                                       unsigned long long* __restrict__ hist, uint32_t hist_len,
                                                       unsigned long long* __restrict__ stats,
                                                       uint32_t* __restrict__ flags) {
     __shared__ unsigned int lhist[32];
-    if (threadIdx.x < 32) lhist[threadIdx.x] = 0;
-    __syncthreads();
-    unsigned long long n_occ = 0, n_rows = 0, n_pairs = 0, n_distinct = 0;
-    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n_tok; t += gridDim.x * 256u) {
-        Walker w;
-        if (!w.init(A, t)) continue;
-        const uint32_t seg = find_segment(S, t);
-        const uint64_t base = S.set_base[seg], mask = S.set_mask[seg];
-        const uint64_t akey = (uint64_t)w.a << 40;
-        uint32_t id, p1 = 0, p2 = 0;
-        bool c, c1 = false, c2 = false, base_window = false;
-        int have = 0, fresh;
-        while (w.next(A, id, c, fresh)) {
-            if (fresh) { have = 0; base_window = fresh < 0; }
-            if (!base_window || c) ++n_rows;  // rows touched: pads + ablated + base span (SURVEY.md 8d r-bar)
-            if (have >= 1 && (c || c1)) {
-                const uint32_t lo = min(id, p1), hi = max(id, p1);
-                const uint32_t nw = set_insert(set, base, mask, akey | ((uint64_t)lo << 20) | hi, flags);
-                n_distinct += nw ? (lo == hi ? 1u : 2u) : 0u;
-                ++n_pairs;
-            }
-            if (have >= 2 && (c || c2)) {
-                const uint32_t lo = min(id, p2), hi = max(id, p2);
-                const uint32_t nw = set_insert(set, base, mask, akey | ((uint64_t)lo << 20) | hi, flags);
-                n_distinct += nw ? (lo == hi ? 1u : 2u) : 0u;
-                ++n_pairs;
-            }
-            p2 = p1; c2 = c1; p1 = id; c1 = c; ++have;
-        }
-        ++n_occ;
-        atomicAdd(&occ[w.a], 1ull);
-        const uint32_t kk = w.k < hist_len ? w.k : hist_len - 1u;
-        if (kk < 32u) atomicAdd(&lhist[kk], 1u); else atomicAdd(&hist[kk], 1ull);
+    if (!INSERT) {
+        if (threadIdx.x < 32) lhist[threadIdx.x] = 0;
+        __syncthreads();
     }
-    __syncthreads();
-    if (threadIdx.x < 32 && threadIdx.x < hist_len && lhist[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)lhist[threadIdx.x]);
+    unsigned long long n_occ = 0, n_rows = 0, n_pairs = 0, n_distinct = 0;
+    const uint32_t n_round = (n_tok + 63u) & ~63u;  // whole waves stay in the loop (wave-level reductions inside)
+    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n_round; t += gridDim.x * 256u) {
+        Walker w;
+        const bool live = t < n_tok && w.init(A, t);
+        const uint32_t seg = t < n_tok ? find_segment(S, t) : 0xFFFFFFFFu;
+        unsigned long long my_pairs = 0;
+        if (live) {
+            const uint64_t base = INSERT ? S.set_base[seg] : 0, mask = INSERT ? S.set_mask[seg] : 0;
+            const uint64_t akey = (uint64_t)w.a << 40;
+            uint32_t id, p1 = 0, p2 = 0;
+            bool c, c1 = false, c2 = false, base_window = false;
+            int have = 0, fresh;
+            while (w.next(A, id, c, fresh)) {
+                if (fresh) { have = 0; base_window = fresh < 0; }
+                if (!base_window || c) ++n_rows;  // rows touched: pads + ablated + base span (SURVEY.md 8d r-bar)
+                if (have >= 1 && (c || c1)) {
+                    if (INSERT) {
+                        const uint32_t lo = min(id, p1), hi = max(id, p1);
+                        const uint32_t nw = set_insert(set, base, mask, akey | ((uint64_t)lo << 20) | hi, flags);
+                        n_distinct += nw ? (lo == hi ? 1u : 2u) : 0u;
+                    }
+                    ++my_pairs;
+                }
+                if (have >= 2 && (c || c2)) {
+                    if (INSERT) {
+                        const uint32_t lo = min(id, p2), hi = max(id, p2);
+                        const uint32_t nw = set_insert(set, base, mask, akey | ((uint64_t)lo << 20) | hi, flags);
+                        n_distinct += nw ? (lo == hi ? 1u : 2u) : 0u;
+                    }
+                    ++my_pairs;
+                }
+                p2 = p1; c2 = c1; p1 = id; c1 = c; ++have;
+            }
+            if (!INSERT) {
+                ++n_occ;
+                atomicAdd(&occ[w.a], 1ull);
+                const uint32_t kk = w.k < hist_len ? w.k : hist_len - 1u;
+                if (kk < 32u) atomicAdd(&lhist[kk], 1u); else atomicAdd(&hist[kk], 1ull);
+            }
+        }
+        n_pairs += my_pairs;
+        if (!INSERT) {
+            // pairs per segment: one atomic per wave when the wave sits inside one segment (the usual case)
+            const uint32_t seg0 = __shfl(seg, 0, 64);
+            if (__all(seg == seg0 || seg == 0xFFFFFFFFu) && seg0 != 0xFFFFFFFFu) {
+                unsigned long long v = my_pairs;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
+                if ((threadIdx.x & 63u) == 0 && v) atomicAdd(&seg_pairs[seg0], v);
+            } else if (my_pairs) {
+                atomicAdd(&seg_pairs[seg], my_pairs);
+            }
+        }
+    }
+    if (!INSERT) {
+        __syncthreads();
+        if (threadIdx.x < 32 && threadIdx.x < hist_len && lhist[threadIdx.x])
+            atomicAdd(&hist[threadIdx.x], (unsigned long long)lhist[threadIdx.x]);
+    }
     // wave-level reduction of the statistics, one atomic per wave
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -432,10 +465,13 @@ __global__ __launch_bounds__(256) void k_ablate_count(WalkArrays A, uint32_t n_t
         n_distinct += __shfl_down(n_distinct, d, 64);
     }
     if ((threadIdx.x & 63u) == 0) {
-        if (n_occ) atomicAdd(&stats[STAT_OCC], n_occ);
-        if (n_rows) atomicAdd(&stats[STAT_ROWS], n_rows);
-        if (n_pairs) atomicAdd(&stats[STAT_PAIRS], n_pairs);
-        if (n_distinct) atomicAdd(&stats[STAT_DISTINCT], n_distinct);
+        if (!INSERT) {
+            if (n_occ) atomicAdd(&stats[STAT_OCC], n_occ);
+            if (n_rows) atomicAdd(&stats[STAT_ROWS], n_rows);
+            if (n_pairs) atomicAdd(&stats[STAT_PAIRS], n_pairs);
+        } else if (n_distinct) {
+            atomicAdd(&stats[STAT_DISTINCT], n_distinct);
+        }
     }
 }
 

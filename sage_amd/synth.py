@@ -88,7 +88,8 @@ def make_lexicon(rng: np.random.Generator, n_types: int, style: str = "en"):
 
 
 def make_corpus(n_lines: int, seed: int = DEFAULT_SEED, style: str = "en", n_types: int | None = None,
-                mean_log_words: float = 4.3, sigma_log_words: float = 0.6, chunk_lines: int = 50_000):
+                mean_log_words: float = 4.3, sigma_log_words: float = 0.6, chunk_lines: int = 50_000,
+                progress=None):
     """Returns (corpus uint8[nbytes], line_offsets int64[n_lines+1]); every line ends with b'.\\n'.
 
     Words/line ~ max(5, LogNormal(mean_log_words, sigma_log_words)) (defaults: ~580 B/line); word types
@@ -130,6 +131,8 @@ def make_corpus(n_lines: int, seed: int = DEFAULT_SEED, style: str = "en", n_typ
         lower = (first >= 97) & (first <= 122)
         flat[line_start[lower]] = first[lower] - 32
         out_chunks.append(flat)
+        if progress is not None and (c0 // chunk_lines) % 4 == 3:
+            progress(f"generated {c0 + nl} lines")
         len_chunks.append(line_end - line_start)
     corpus = np.concatenate(out_chunks) if len(out_chunks) > 1 else out_chunks[0]
     lens = np.concatenate(len_chunks)
