@@ -1,0 +1,151 @@
+"""CPU: host logic of the product (no GPU, no compute calls): file formats against the reference's golden files,
+segment rule against the oracle, the C-ABI library loads and exports every symbol of include/sage_hip.h."""
+import json
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from oracle import sage_oracle as orc
+from tests.golden_io import load_json_gz, load_npz
+
+REPO = Path(__file__).resolve().parent.parent
+
+
+def test_library_exports_every_declared_symbol():
+    from sage_amd import _lib
+    header = (REPO / "include" / "sage_hip.h").read_text()
+    declared = set(re.findall(r"\b(sage_[a-z_]+)\s*\(", header))
+    declared.discard("sage_ctx")
+    assert declared == set(_lib.EXPORTED)
+    lib = _lib.load()
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.sage_version().decode().count(".") == 2
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from sage_amd._lib import HipSage, SageHipError
+    with pytest.raises(SageHipError):
+        HipSage(0)
+
+
+def test_product_does_not_import_oracle():
+    for p in (REPO / "sage_amd").rglob("*.py"):
+        text = p.read_text()
+        assert "oracle" not in text.replace("sage_oracle", "oracle") or "import oracle" not in text, p
+        assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), p
+
+
+@pytest.mark.parametrize("n,w,flush", [(8, 4, 10000), (25, 1, 10), (11, 1, 10), (12, 1, 10), (20600, 1, 10000),
+                                        (20600, 3, 10000), (20600, 4, 10000), (61, 1, 7), (3, 8, 10000), (1, 1, 5),
+                                        (100, 7, 3)])
+def test_segment_bounds_match_oracle(n, w, flush):
+    from sage_amd.parallel import divide_data_by_num, segment_line_bounds
+    b = segment_line_bounds(n, w, flush)
+    segs = list(zip(b[:-1].tolist(), b[1:].tolist()))
+    assert segs == orc.segment_bounds(n, w, flush)
+    assert [len(x) for x in divide_data_by_num(list(range(n)), w)] == [hi - lo for lo, hi in orc.shard_bounds(n, w)]
+
+
+def test_shard_sizes_match_reference_golden():
+    from sage_amd.parallel import divide_data_by_num
+    g = load_npz("parallel.npz")
+    for (n, w), want in zip(g["shard_cases"].tolist(), g["shard_sizes"].tolist()):
+        assert ",".join(str(len(b)) for b in divide_data_by_num(list(range(n)), w)) == want
+
+
+def test_vocab_and_loss_file_formats(tmp_path):
+    """write_vocab / load_vocab / save_sorted_losses / save_stats reproduce the reference's files byte for byte."""
+    from sage_amd import hostio
+    from sage_amd.tokenizer import SaGeTokenizer
+    g = load_json_gz("build_vocab.json.gz")
+    files = g["files"]
+    vocab = [bytes.fromhex(h) for h in g["vocab"]]
+    init = tmp_path / "initial.vocab"
+    hostio.write_vocab({k: i for i, k in enumerate(vocab)}, init)
+    assert init.read_text() == "".join(h + "\n" for h in g["vocab"])
+    assert hostio.load_vocab(init) == vocab
+    with pytest.raises(FileNotFoundError):
+        hostio.load_vocab(tmp_path / "absent.vocab")
+    # rebuild the first round's files from its golden sorted-loss file
+    model = SaGeTokenizer.__new__(SaGeTokenizer)      # host state only; no GPU
+    from sage_amd.hf_bytes import HFEncoding
+    model.hfe = HFEncoding()
+    model.vocab_version = 0
+    model.max_len = 16
+    model.set_vocabulary(vocab)
+    want = files["sage_vocabs/sorted_losses_before_2300.txt"]
+    ranked = []
+    for ln in want.splitlines():
+        tok, val = ln.rsplit("\t", 1)
+        ranked.append((float(val), model.str_vocab[tok]))
+    hostio.save_sorted_losses(model, ranked, 2300, tmp_path)
+    assert (tmp_path / "sorted_losses_before_2300.txt").read_text(encoding="utf-8") == want
+    assert (tmp_path / "worst_500_2300.txt").read_text(encoding="utf-8") == files["sage_vocabs/worst_500_2300.txt"]
+    assert (tmp_path / "best_500_2300.txt").read_text(encoding="utf-8") == files["sage_vocabs/best_500_2300.txt"]
+    stats = json.loads(files["stats/stats_2300.json"])
+    hostio.save_stats(stats, tmp_path, 2300)
+    assert (tmp_path / "stats_2300.json").read_text() == files["stats/stats_2300.json"]
+    # prune selection (SaGeVocabBuilder.py:146,159) from the golden ranking reproduces deleted_vocab
+    n_prune = stats["num_tokens_to_prune"]
+    doomed = {model.id_to_bytes(tid) for _, tid in sorted(ranked)[:n_prune]}
+    deleted = {t: i for t, i in model.get_vocabulary().items() if t in doomed}
+    hostio.write_vocab(deleted, tmp_path / "deleted.vocab")
+    assert (tmp_path / "deleted.vocab").read_text() == files["sage_vocabs/deleted_vocab_2300.vocab"]
+
+
+def test_tokenizer_vocab_state_matches_reference_rules():
+    from sage_amd.hf_bytes import HFEncoding
+    from sage_amd.tokenizer import SaGeTokenizer
+    vocab = [bytes([i]) for i in range(256)] + [b"ab", b"abc", b"ab"]   # a repeated key keeps its LAST position
+    t = SaGeTokenizer(vocab, 16)
+    assert t.vocab_size() == 258 and t.get_vocabulary()[b"ab"] == 258 and t.id_to_bytes(257) == b"abc"
+    keys, ids = t.key_table()
+    assert dict(zip(keys, ids.tolist())) == t.get_vocabulary()
+    d = {}
+    t.add_all_byte_ids(d, 1e6)
+    assert len(d) == 256 and set(d.values()) == {1e6}
+    with pytest.raises(Exception, match="missing byte"):
+        SaGeTokenizer(vocab[1:], 16)
+    with pytest.raises(AssertionError):
+        SaGeTokenizer(vocab + ["str"], 16)
+    assert HFEncoding().to_encoded(b" a\n") == "ĠaĊ"
+
+
+def test_load_corpus_shuffle_and_cache(tmp_path):
+    import random
+    from sage_amd import hostio, setSageFolder
+    setSageFolder(tmp_path)
+    lines = [f"line {i}\n" for i in range(2500)]
+    (tmp_path / "c.txt").write_text("".join(lines))
+    random.seed(7)
+    got = hostio.load_corpus(tmp_path / "c.txt", None, 2)
+    random.seed(7)
+    want = list(lines)
+    random.shuffle(want)
+    assert got == want[:2000]
+    cached = tmp_path / "data" / "c_2000.txt"
+    assert cached.read_text() == "".join(want[:2000])
+    assert hostio.load_corpus(tmp_path / "c.txt", cached, 2) == want[:2000]
+
+
+def test_partition_segments_balanced_and_whole():
+    from sage_amd.dist import partition_segments
+    from sage_amd.parallel import segment_line_bounds
+    rng = np.random.default_rng(0)
+    lens = rng.integers(1, 400, size=53_123)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    bounds = segment_line_bounds(len(lens), 4)
+    for world in (1, 2, 3, 4, 8):
+        parts = partition_segments(bounds, off, world)
+        assert parts[0][0] == 0 and parts[-1][1] == len(bounds) - 1
+        assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+        sizes = [off[bounds[hi]] - off[bounds[lo]] for lo, hi in parts]
+        assert sum(sizes) == off[-1]
+        if world > 1:
+            assert max(sizes) <= off[-1] / world + (off[bounds[1:]] - off[bounds[:-1]]).max()
