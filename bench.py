@@ -167,8 +167,10 @@ def main():
             "walk": st["corpus_bytes"] * 8 / max(1.0, b_bar) * 2 + tokens_local * 8,
             "count": st["records"] * 8 * 2,
             "score": st["rows"] * args.dim * 8,
+            "describe": st["corpus_bytes"] * 8 + tokens_local * (8 + 64),
+            "pairs": tokens_local * (args.dim * 8 + 16),
         }
-        dom = max(("match", "walk", "count", "score"), key=lambda k: kt[k][0])
+        dom = max(per_kernel_bytes, key=lambda k: kt[k][0])
         dom_ms, dom_n = kt[dom]
         launches_per_step = max(1, dom_n // args.steps)
         avg_ms = dom_ms / max(1, dom_n)

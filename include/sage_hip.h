@@ -109,13 +109,17 @@ int sage_ablation_step_device(sage_ctx* ctx, const int64_t* segment_line_bounds,
  * the number of launches and the summed milliseconds since the last sage_reset_kernel_times.
  */
 enum { SAGE_K_MATCH = 0, SAGE_K_WALK = 1, SAGE_K_SCAN = 2, SAGE_K_COUNT = 3, SAGE_K_SCORE = 4, SAGE_K_MISC = 5,
-       SAGE_K_NCLASSES = 6 };
+       SAGE_K_DESCRIBE = 6, SAGE_K_PAIRS = 7, SAGE_K_NCLASSES = 8 };
 int sage_set_profiling(sage_ctx* ctx, int enabled);
 int sage_reset_kernel_times(sage_ctx* ctx);
 int sage_get_kernel_times(sage_ctx* ctx, double* out_ms /*[SAGE_K_NCLASSES]*/, int64_t* out_launches /*[SAGE_K_NCLASSES]*/);
 
 /* Tunables: scratch is sized for batches of at most `bytes` corpus bytes (default 256 MiB). */
 int sage_set_batch_bytes(sage_ctx* ctx, int64_t bytes);
+
+/* Distinct-key counting back end: 0 = hash partition + LDS dedupe (default), 1 = per-segment sets in HBM (the
+ * fallback the library takes by itself if an LDS set ever overflows).  Results are identical. */
+int sage_set_count_mode(sage_ctx* ctx, int mode);
 
 /* Workload statistics of the last step, for the roofline's algorithmic bytes:
  * out[0]=tokens, out[1]=corpus bytes, out[2]=ablated occurrences, out[3]=embedding rows touched,

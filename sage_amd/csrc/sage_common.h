@@ -40,6 +40,19 @@ SAGE_HD uint64_t sage_mix64(uint64_t k) {
 #define SAGE_M_ID(w) ((w) & SAGE_ID_MASK)
 #define SAGE_M_LEN(w) ((w) >> 20)
 
-// Token word: id | min(index in line, 3) << 20
+// Token word: id | min(index in line, 3) << 20 | min(tokens after it in the line, 3) << 22
 #define SAGE_T_ID(w) ((w) & SAGE_ID_MASK)
 #define SAGE_T_LOC3(w) (((w) >> 20) & 3u)
+#define SAGE_T_AFTER3(w) (((w) >> 22) & 3u)
+
+// Occurrence descriptor: 16 u32 per base token.  word 0 = header, words 1.. = the ablated window
+// [left pads | x1..xk | right pads] (at most SAGE_DESC_MAXWIN ids, otherwise OVER is set and the slow path runs).
+#define SAGE_DESC_WORDS 16
+#define SAGE_DESC_MAXWIN 15
+#define SAGE_DH_VALID 0x80000000u
+#define SAGE_DH_OVER 0x40000000u
+#define SAGE_DH_NEVER 0x20000000u
+#define SAGE_DH_K(h) ((h) & 0xFFFu)
+#define SAGE_DH_M(h) (((h) >> 12) & 0xFFFu)
+#define SAGE_DH_PL(h) (((h) >> 24) & 3u)
+#define SAGE_DH_PR(h) (((h) >> 26) & 3u)

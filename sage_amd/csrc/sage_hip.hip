@@ -10,6 +10,8 @@
 #include "../../include/sage_hip.h"
 #include "sage_common.h"
 #include "sage_kernels.h"
+#include "sage_kernels2.h"
+#include "sage_kernels3.h"
 
 #define SAGE_VERSION_STR "0.1.0"
 
@@ -50,7 +52,8 @@ struct sage_ctx {
     bool have_emb = false;
 
     // scratch (grow-only; nothing is allocated in the steady state)
-    DevBuf M, ntok, tokoff, tile_sums, grand_total, tok_w0, tok_pos, set, seg_line_rel, seg_tok_off, set_base, set_mask, seg_pairs;
+    DevBuf M, ntok, tokoff, tile_sums, grand_total, tok_w0, tok_pos, set, seg_line_rel, seg_tok_off, set_base, set_mask, seg_pairs, desc, gcache, over_list, over_count, hist1, bucket_off, rec_a, rec_b;
+    int count_mode = 0;  // 0 = partition + LDS dedupe (v2), 1 = per-segment HBM sets (v1, also the overflow fallback)
     DevBuf ex_ids, ex_starts, ex_widths;
     DevBuf loss, occ, hist, stats, flags;
     int64_t batch_bytes = 256ll << 20;
@@ -197,11 +200,25 @@ int check_ready(sage_ctx* c, bool need_emb) {
 }
 
 template <int G, int EPL>
-void launch_score(sage_ctx* c, const WalkArrays& A, uint32_t n_tok) {
+void launch_score(sage_ctx* c, const WalkArrays& A, uint32_t n_tok, bool have_over) {
     const uint32_t gpb = 256 / G;
-    const uint32_t grid = std::min<uint32_t>(cdiv(n_tok, gpb), 256u * 16u);
-    k_score<G, EPL><<<grid, 256, 0, c->stream>>>(A, n_tok, c->emb.as<double>(), (uint32_t)c->emb_rows,
-                                                 (uint32_t)c->dp, c->loss.as<double>(), c->flags.as<uint32_t>());
+    {
+        Prof p(c, SAGE_K_PAIRS);
+        const uint32_t grid = std::min<uint32_t>(cdiv(cdiv(n_tok, 4), gpb), 256u * 16u);
+        k_pair_cache<G, EPL><<<grid, 256, 0, c->stream>>>(A.tok_w0, n_tok, c->emb.as<double>(), (uint32_t)c->emb_rows,
+                                                          (uint32_t)c->dp, c->gcache.as<double2>(), c->flags.as<uint32_t>());
+    }
+    {
+        Prof p(c, SAGE_K_SCORE);
+        const uint32_t grid = std::min<uint32_t>(cdiv(n_tok, 256), 256u * 8u);
+        k_score_desc<G, EPL><<<grid, 256, 0, c->stream>>>(c->desc.as<uint4>(), A.tok_w0, n_tok, c->emb.as<double>(),
+                                                          (uint32_t)c->emb_rows, (uint32_t)c->dp, c->gcache.as<double2>(),
+                                                          c->loss.as<double>(), c->flags.as<uint32_t>());
+        if (have_over)  // windows longer than a descriptor: the streaming walker scores them
+            k_score<G, EPL><<<64, 256, 0, c->stream>>>(A, n_tok, c->emb.as<double>(), (uint32_t)c->emb_rows, (uint32_t)c->dp,
+                                                       c->loss.as<double>(), c->flags.as<uint32_t>(),
+                                                       c->over_list.as<uint32_t>(), c->over_count.as<uint32_t>());
+    }
 }
 
 int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, int64_t vsize, int64_t hist_len,
@@ -270,19 +287,67 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
             if ((rc = ensure(c, c->set_base, (size_t)nsb * 8))) return rc;
             if ((rc = ensure(c, c->set_mask, (size_t)nsb * 8))) return rc;
             if ((rc = ensure(c, c->seg_pairs, (size_t)nsb * 8))) return rc;
+            if ((rc = ensure(c, c->desc, (size_t)n_tok * SAGE_DESC_WORDS * 4))) return rc;
+            if ((rc = ensure(c, c->gcache, (size_t)n_tok * 16))) return rc;
+            if ((rc = ensure(c, c->over_list, (size_t)n_tok * 4))) return rc;
+            if ((rc = ensure(c, c->over_count, 4))) return rc;
             HIP_TRY(c, hipMemsetAsync(c->seg_pairs.p, 0, (size_t)nsb * 8, c->stream));
+            HIP_TRY(c, hipMemsetAsync(c->over_count.p, 0, 4, c->stream));
             SegPlan S{c->seg_tok_off.as<uint32_t>(), c->set_base.as<uint64_t>(), c->set_mask.as<uint64_t>(), nsb};
             const uint32_t cgrid = std::min<uint32_t>(cdiv(n_tok, 256), 256u * 16u);
             {
-                Prof p(c, SAGE_K_COUNT);
-                k_ablate_count<false><<<cgrid, 256, 0, c->stream>>>(
-                    A, n_tok, S, nullptr, c->seg_pairs.as<unsigned long long>(), c->occ.as<unsigned long long>(),
-                    c->hist.as<unsigned long long>(), (uint32_t)hist_len, c->stats.as<unsigned long long>(),
-                    c->flags.as<uint32_t>());
+                Prof p(c, SAGE_K_DESCRIBE);
+                k_describe<<<cgrid, 256, 0, c->stream>>>(
+                    A, n_tok, S, c->desc.as<uint4>(), c->seg_pairs.as<unsigned long long>(),
+                    c->occ.as<unsigned long long>(), c->hist.as<unsigned long long>(), (uint32_t)hist_len,
+                    c->stats.as<unsigned long long>(), c->over_list.as<uint32_t>(), c->over_count.as<uint32_t>());
             }
-            // one distinct-key set per segment, sized from the exact pair count: load factor <= 0.5
+            uint32_t n_over = 0;
+            if (c->count_mode == 0) {
+                // ---- v2: hash-partition the key stream, dedupe each bucket in LDS ----
+                const size_t nbk = (size_t)nsb * NB1;
+                if ((rc = ensure(c, c->hist1, nbk * 8))) return rc;
+                if ((rc = ensure(c, c->bucket_off, (nbk + 1) * 8))) return rc;
+                HIP_TRY(c, hipMemsetAsync(c->hist1.p, 0, nbk * 8, c->stream));
+                {
+                    Prof p(c, SAGE_K_COUNT);
+                    k_key_partition<0><<<cgrid, 256, 0, c->stream>>>(c->desc.as<uint4>(), A.tok_w0, n_tok, S,
+                                                                     c->hist1.as<unsigned long long>(), nullptr);
+                    k_key_partition_over<0><<<64, 256, 0, c->stream>>>(A, n_tok, S, c->over_list.as<uint32_t>(),
+                                                                       c->over_count.as<uint32_t>(),
+                                                                       c->hist1.as<unsigned long long>(), nullptr);
+                }
+                std::vector<uint64_t> h1(nbk), boff(nbk + 1);
+                HIP_TRY(c, hipMemcpyAsync(h1.data(), c->hist1.p, nbk * 8, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipMemcpyAsync(&n_over, c->over_count.p, 4, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                uint64_t total = 0;
+                for (size_t i = 0; i < nbk; ++i) { boff[i] = total; total += h1[i]; }
+                boff[nbk] = total;
+                if ((rc = ensure(c, c->rec_a, std::max<uint64_t>(total, 1) * 8))) return rc;
+                if ((rc = ensure(c, c->rec_b, std::max<uint64_t>(total, 1) * 8))) return rc;
+                HIP_TRY(c, hipMemcpyAsync(c->bucket_off.p, boff.data(), (nbk + 1) * 8, hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(c, hipMemcpyAsync(c->hist1.p, boff.data(), nbk * 8, hipMemcpyHostToDevice, c->stream));  // cursors
+                {
+                    Prof p(c, SAGE_K_COUNT);
+                    k_key_partition<1><<<cgrid, 256, 0, c->stream>>>(c->desc.as<uint4>(), A.tok_w0, n_tok, S,
+                                                                     c->hist1.as<unsigned long long>(),
+                                                                     c->rec_a.as<unsigned long long>());
+                    k_key_partition_over<1><<<64, 256, 0, c->stream>>>(A, n_tok, S, c->over_list.as<uint32_t>(),
+                                                                       c->over_count.as<uint32_t>(),
+                                                                       c->hist1.as<unsigned long long>(),
+                                                                       c->rec_a.as<unsigned long long>());
+                    const uint32_t dgrid = (uint32_t)std::min<size_t>(nbk, 256u * 4u);
+                    k_key_dedupe<<<dgrid, 256, 0, c->stream>>>(c->bucket_off.as<unsigned long long>(), (uint32_t)nbk,
+                                                               c->rec_a.as<unsigned long long>(),
+                                                               c->rec_b.as<unsigned long long>(),
+                                                               c->stats.as<unsigned long long>(), c->flags.as<uint32_t>());
+                }
+            } else {
+            // ---- v1: one distinct-key set per segment in HBM, sized from the exact pair count: load factor <= 0.5
             std::vector<uint64_t> sbase(nsb), smask(nsb), spairs(nsb);
             HIP_TRY(c, hipMemcpyAsync(spairs.data(), c->seg_pairs.p, (size_t)nsb * 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(&n_over, c->over_count.p, 4, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             uint64_t slots = 0;
             for (uint32_t s = 0; s < nsb; ++s) {
@@ -298,20 +363,25 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
             }
             {
                 Prof p(c, SAGE_K_COUNT);
-                k_ablate_count<true><<<cgrid, 256, 0, c->stream>>>(
-                    A, n_tok, S, c->set.as<unsigned long long>(), nullptr, nullptr, nullptr, (uint32_t)hist_len,
-                    c->stats.as<unsigned long long>(), c->flags.as<uint32_t>());
+                k_count_desc<<<cgrid, 256, 0, c->stream>>>(c->desc.as<uint4>(), A.tok_w0, n_tok, S,
+                                                           c->set.as<unsigned long long>(),
+                                                           c->stats.as<unsigned long long>(), c->flags.as<uint32_t>());
+                if (n_over)
+                    k_ablate_count<true><<<64, 256, 0, c->stream>>>(
+                        A, n_tok, S, c->set.as<unsigned long long>(), nullptr, nullptr, nullptr, (uint32_t)hist_len,
+                        c->stats.as<unsigned long long>(), c->flags.as<uint32_t>(), c->over_list.as<uint32_t>(),
+                        c->over_count.as<uint32_t>());
+            }
             }
             {
-                Prof p(c, SAGE_K_SCORE);
                 const int dp = c->dp;
-                if (dp <= 32) launch_score<8, 4>(c, A, n_tok);
-                else if (dp <= 56) launch_score<8, 7>(c, A, n_tok);
-                else if (dp <= 64) launch_score<8, 8>(c, A, n_tok);
-                else if (dp <= 128) launch_score<16, 8>(c, A, n_tok);
-                else if (dp <= 256) launch_score<32, 8>(c, A, n_tok);
-                else if (dp <= 320) launch_score<32, 10>(c, A, n_tok);
-                else launch_score<64, 8>(c, A, n_tok);
+                const bool ov = n_over > 0;
+                if (dp <= 32) launch_score<8, 4>(c, A, n_tok, ov);
+                else if (dp <= 64) launch_score<8, 8>(c, A, n_tok, ov);
+                else if (dp <= 128) launch_score<32, 4>(c, A, n_tok, ov);
+                else if (dp <= 256) launch_score<64, 4>(c, A, n_tok, ov);
+                else if (dp <= 384) launch_score<64, 6>(c, A, n_tok, ov);
+                else launch_score<64, 8>(c, A, n_tok, ov);
             }
             HIP_TRY(c, hipGetLastError());
             sa = sb;
@@ -325,8 +395,8 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
         if (flags[FLAG_EMPTY_LINE])
             return fail(c, SAGE_E_EMPTY_LINE, "not enough values to unpack (expected 3, got 0)");
         if (flags[FLAG_SET_OVERFLOW]) {
-            if (attempt >= 4) return fail(c, SAGE_E_LIMIT, "distinct-key set overflowed after 4 regrowths");
-            c->set_factor *= 2;  // exactness first: redo the step with larger sets
+            if (attempt >= 1 || c->count_mode == 1) return fail(c, SAGE_E_LIMIT, "distinct-key set overflowed");
+            c->count_mode = 1;   // exactness first: an LDS set overflowed (adversarial hash skew) -> redo with HBM sets
             continue;
         }
         if (flags[FLAG_ROW_OOB])
@@ -373,7 +443,7 @@ void sage_destroy(sage_ctx* c) {
     for (auto e : c->ev_free) (void)hipEventDestroy(e);
     DevBuf* all[] = {&c->buckets, &c->keys, &c->byte_id, &c->corpus, &c->rem, &c->line_off, &c->emb, &c->M, &c->ntok,
                      &c->tokoff, &c->tile_sums, &c->grand_total, &c->tok_w0, &c->tok_pos, &c->set, &c->seg_line_rel,
-                     &c->seg_tok_off, &c->set_base, &c->set_mask, &c->seg_pairs, &c->ex_ids, &c->ex_starts, &c->ex_widths, &c->loss,
+                     &c->seg_tok_off, &c->set_base, &c->set_mask, &c->seg_pairs, &c->desc, &c->gcache, &c->over_list, &c->over_count, &c->hist1, &c->bucket_off, &c->rec_a, &c->rec_b, &c->ex_ids, &c->ex_starts, &c->ex_widths, &c->loss,
                      &c->occ, &c->hist, &c->stats, &c->flags};
     for (DevBuf* b : all) release(*b);
     (void)hipStreamDestroy(c->stream);
@@ -474,7 +544,7 @@ int sage_set_embeddings(sage_ctx* c, const double* emb, int64_t rows, int32_t di
     if (!c || !emb || rows <= 0 || dim <= 0) return fail(c, SAGE_E_ARG, "bad argument");
     if (dim > 512) return fail(c, SAGE_E_LIMIT, "embedding dimension above 512 is not supported");
     HIP_TRY(c, hipSetDevice(c->device));
-    const int dp = (dim + 7) / 8 * 8;
+    const int dp = dim <= 32 ? (dim + 7) / 8 * 8 : (dim + 15) / 16 * 16;  // whole 128-B lines per lane group
     int rc;
     if ((rc = ensure(c, c->emb, (size_t)rows * dp * 8))) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -588,6 +658,12 @@ int sage_get_kernel_times(sage_ctx* c, double* out_ms, int64_t* out_launches) {
 int sage_set_batch_bytes(sage_ctx* c, int64_t bytes) {
     if (!c || bytes < 4096) return fail(c, SAGE_E_ARG, "batch_bytes must be at least 4096");
     c->batch_bytes = std::min<int64_t>(bytes, 0xF0000000ll);
+    return SAGE_OK;
+}
+
+int sage_set_count_mode(sage_ctx* c, int mode) {
+    if (!c || (mode != 0 && mode != 1)) return fail(c, SAGE_E_ARG, "count mode must be 0 or 1");
+    c->count_mode = mode;
     return SAGE_OK;
 }
 

@@ -150,6 +150,7 @@ __global__ __launch_bounds__(256) void k_walk_write(const int64_t* __restrict__ 
     const uint32_t p_begin = (uint32_t)(line_off[line0 + l] - pos0);
     uint32_t p = p_begin, e = (uint32_t)(line_off[line0 + l + 1] - pos0);
     uint32_t t = tok_off[l], c = 0;
+    const uint32_t nt = tok_off[l + 1] - t;
     while (p < e) {
         const uint32_t m = M[p].x;
         if (EXPORT) {
@@ -157,7 +158,8 @@ __global__ __launch_bounds__(256) void k_walk_write(const int64_t* __restrict__ 
             ex_starts[t] = (int32_t)(p - p_begin);
             ex_widths[t] = (int32_t)SAGE_M_LEN(m);
         } else {
-            tok_w0[t] = SAGE_M_ID(m) | ((c < 3u ? c : 3u) << 20);
+            const uint32_t after = nt - 1u - c;
+            tok_w0[t] = SAGE_M_ID(m) | ((c < 3u ? c : 3u) << 20) | ((after < 3u ? after : 3u) << 22);
             tok_pos[t] = p;
         }
         p += SAGE_M_LEN(m);
@@ -390,15 +392,19 @@ __global__ __launch_bounds__(256) void k_ablate_count(WalkArrays A, uint32_t n_t
                                                       unsigned long long* __restrict__ occ,
                                                       unsigned long long* __restrict__ hist, uint32_t hist_len,
                                                       unsigned long long* __restrict__ stats,
-                                                      uint32_t* __restrict__ flags) {
+                                                      uint32_t* __restrict__ flags,
+                                                      const uint32_t* __restrict__ list = nullptr,
+                                                      const uint32_t* __restrict__ n_list = nullptr) {
     __shared__ unsigned int lhist[32];
+    const uint32_t n_items = list ? *n_list : n_tok;   // optional indirection: only the listed tokens
     if (!INSERT) {
         if (threadIdx.x < 32) lhist[threadIdx.x] = 0;
         __syncthreads();
     }
     unsigned long long n_occ = 0, n_rows = 0, n_pairs = 0, n_distinct = 0;
-    const uint32_t n_round = (n_tok + 63u) & ~63u;  // whole waves stay in the loop (wave-level reductions inside)
-    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n_round; t += gridDim.x * 256u) {
+    const uint32_t n_round = (n_items + 63u) & ~63u;  // whole waves stay in the loop (wave-level reductions inside)
+    for (uint32_t it = blockIdx.x * 256u + threadIdx.x; it < n_round; it += gridDim.x * 256u) {
+        const uint32_t t = it < n_items ? (list ? list[it] : it) : 0xFFFFFFFFu;
         Walker w;
         const bool live = t < n_tok && w.init(A, t);
         const uint32_t seg = t < n_tok ? find_segment(S, t) : 0xFFFFFFFFu;
@@ -490,16 +496,20 @@ __device__ __forceinline__ double log_sigmoid(double x) {
 template <int G, int EPL>
 __global__ __launch_bounds__(256) void k_score(WalkArrays A, uint32_t n_tok, const double* __restrict__ emb,
                                                uint32_t emb_rows, uint32_t dp, double* __restrict__ loss,
-                                               uint32_t* __restrict__ flags) {
+                                               uint32_t* __restrict__ flags,
+                                               const uint32_t* __restrict__ list = nullptr,
+                                               const uint32_t* __restrict__ n_list = nullptr) {
+    const uint32_t n_items = list ? *n_list : n_tok;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t gl = lane % G;                       // lane inside the group
     const uint32_t groups_per_block = 256 / G;
     const uint32_t group0 = blockIdx.x * groups_per_block + threadIdx.x / G;
     const uint32_t group_stride = gridDim.x * groups_per_block;
 
-    for (uint32_t t0 = blockIdx.x * groups_per_block; t0 < n_tok; t0 += group_stride) {
-        const uint32_t t = t0 + threadIdx.x / G;
-        (void)group0;
+    for (uint32_t t0 = blockIdx.x * groups_per_block; t0 < n_items; t0 += group_stride) {
+        const uint32_t it = t0 + threadIdx.x / G;
+        const uint32_t t = it < n_items ? (list ? list[it] : it) : 0xFFFFFFFFu;
+        (void)group0; (void)lane;
         Walker w;
         bool active = t < n_tok && w.init(A, t);
         double r0[EPL], r1[EPL], r2[EPL];

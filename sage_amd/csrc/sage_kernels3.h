@@ -1,0 +1,246 @@
+// Distinct (ablated, target, context) keys per count segment, v2: hash-partition the key stream into buckets that
+// fit an LDS set, then deduplicate each bucket on chip.  Everything is a coalesced stream over HBM; no global
+// atomics per key (v1 = one random 64-bit CAS per key into an HBM-resident set).
+//
+//   k_key_hist     keys regenerated from descriptors -> counts per (segment, coarse bucket)           [read desc]
+//   (host prefix sum of the 64 x n_seg counters)
+//   k_key_scatter  keys regenerated again -> written into their coarse bucket's region                 [read desc, write rec]
+//   k_key_dedupe   one block per coarse bucket: LDS histogram -> fine buckets (second buffer) -> LDS set per fine
+//                  bucket, counts new keys (weight 2, or 1 when target == context)                     [read rec x3, write rec]
+#pragma once
+#include "sage_kernels2.h"
+
+#define NB1 64           // coarse buckets per count segment
+#define FINE_TARGET 1536 // records per fine bucket aimed at
+#define SET_SLOTS 4096   // LDS set capacity (u64 slots, 32 KiB)
+#define SET_FILL 2048    // at most this many records are offered to one set pass (load <= 0.5)
+#define NB2_MAX 256
+
+// Calls f(lo, hi) for every position pair of the occurrence's two windows (model.py:115-136 via descriptors).
+template <class F>
+__device__ __forceinline__ void keys_from_desc(const uint32_t (&d)[16], const uint32_t* __restrict__ tok_w0, uint32_t t,
+                                               F&& f) {
+    const uint32_t hdr = d[0];
+    const uint32_t k = SAGE_DH_K(hdr), m = SAGE_DH_M(hdr), pl = SAGE_DH_PL(hdr), pr = SAGE_DH_PR(hdr);
+    const uint32_t L = pl + k + pr;
+#pragma unroll
+    for (int j = 1; j < SAGE_DESC_MAXWIN; ++j) {
+        if ((uint32_t)j < L) {
+            const bool c = (uint32_t)j >= pl && (uint32_t)j < pl + k;
+            const bool c1 = (uint32_t)(j - 1) >= pl && (uint32_t)(j - 1) < pl + k;
+            if (c || c1) f(min(d[1 + j], d[j]), max(d[1 + j], d[j]));
+            if (j >= 2) {
+                const bool c2 = (uint32_t)(j - 2) >= pl && (uint32_t)(j - 2) < pl + k;
+                if (c || c2) f(min(d[1 + j], d[j - 1]), max(d[1 + j], d[j - 1]));
+            }
+        }
+    }
+    const uint32_t w0 = t - pl, w1 = t + m + pr;  // base window tokens [w0, w1), centre [t, t+m)
+    uint32_t p1 = 0, p2 = 0;
+    for (uint32_t i = w0; i < w1; ++i) {
+        const uint32_t id = SAGE_T_ID(tok_w0[i]);
+        const bool c = i >= t && i < t + m;
+        if (i >= w0 + 1) { const bool c1 = (i - 1) >= t && (i - 1) < t + m; if (c || c1) f(min(id, p1), max(id, p1)); }
+        if (i >= w0 + 2) { const bool c2 = (i - 2) >= t && (i - 2) < t + m; if (c || c2) f(min(id, p2), max(id, p2)); }
+        p2 = p1; p1 = id;
+    }
+}
+
+// Same pairs for a window too long for a descriptor: stream the walker.
+template <class F>
+__device__ __forceinline__ void keys_from_walk(const WalkArrays& A, Walker& w, F&& f) {
+    uint32_t id, p1 = 0, p2 = 0;
+    bool c, c1 = false, c2 = false;
+    int have = 0, fresh;
+    while (w.next(A, id, c, fresh)) {
+        if (fresh) have = 0;
+        if (have >= 1 && (c || c1)) f(min(id, p1), max(id, p1));
+        if (have >= 2 && (c || c2)) f(min(id, p2), max(id, p2));
+        p2 = p1; c2 = c1; p1 = id; c1 = c; ++have;
+    }
+}
+
+__device__ __forceinline__ void load_desc(const uint4* __restrict__ desc, uint32_t t, uint32_t (&d)[16]) {
+    const uint4 a = desc[(size_t)t * 4], b = desc[(size_t)t * 4 + 1], c = desc[(size_t)t * 4 + 2], e = desc[(size_t)t * 4 + 3];
+    d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+    d[8] = c.x; d[9] = c.y; d[10] = c.z; d[11] = c.w; d[12] = e.x; d[13] = e.y; d[14] = e.z; d[15] = e.w;
+}
+
+__device__ __forceinline__ uint64_t make_key(uint32_t a, uint32_t lo, uint32_t hi) {
+    return ((uint64_t)a << 40) | ((uint64_t)lo << 20) | hi;
+}
+
+// ---- pass 1: counts per (segment, coarse bucket) ------------------------------------------------------------
+// MODE 0: count into hist1.  MODE 1: scatter into rec using cursor (which starts at each bucket's base offset).
+// A tile of 256 consecutive tokens touches at most two segments in practice; those go through LDS counters and
+// one global atomic per (tile, bucket); anything else takes one global atomic per key.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_key_partition(const uint4* __restrict__ desc, const uint32_t* __restrict__ tok_w0,
+                                                       uint32_t n_tok, SegPlan S, unsigned long long* __restrict__ counters,
+                                                       unsigned long long* __restrict__ rec) {
+    __shared__ unsigned int cnt[2][NB1];
+    __shared__ unsigned long long gbase[2][NB1];
+    const uint32_t n_round = (n_tok + 255u) & ~255u;
+    for (uint32_t base = blockIdx.x * 256u; base < n_round; base += gridDim.x * 256u) {
+        const uint32_t t = base + threadIdx.x;
+        if (threadIdx.x < 2 * NB1) cnt[threadIdx.x / NB1][threadIdx.x % NB1] = 0;
+        const uint32_t s0 = find_segment(S, base);
+        uint32_t d[16];
+        bool live = false;
+        uint32_t seg = 0, a = 0;
+        if (t < n_tok) {
+            load_desc(desc, t, d);
+            live = (d[0] & SAGE_DH_VALID) && !(d[0] & SAGE_DH_OVER);
+            if (live) { seg = find_segment(S, t); a = SAGE_T_ID(tok_w0[t]); }
+        }
+        const bool local = live && (seg - s0) < 2u;
+        __syncthreads();
+        if (live) {
+            keys_from_desc(d, tok_w0, t, [&](uint32_t lo, uint32_t hi) {
+                const uint64_t key = make_key(a, lo, hi);
+                const uint32_t b1 = (uint32_t)sage_mix64(key) & (NB1 - 1);
+                if (local) atomicAdd(&cnt[seg - s0][b1], 1u);
+                else if (MODE == 0) atomicAdd(&counters[(size_t)seg * NB1 + b1], 1ull);
+                else rec[atomicAdd(&counters[(size_t)seg * NB1 + b1], 1ull)] = key;
+            });
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * NB1) {
+            const uint32_t ls = threadIdx.x / NB1, b = threadIdx.x % NB1;
+            const uint32_t n = cnt[ls][b];
+            if (n && (s0 + ls) < S.n_seg) {
+                const unsigned long long old = atomicAdd(&counters[(size_t)(s0 + ls) * NB1 + b], (unsigned long long)n);
+                if (MODE == 1) gbase[ls][b] = old;
+            }
+            if (MODE == 1) cnt[ls][b] = 0;
+        }
+        if (MODE == 1) {
+            __syncthreads();
+            if (local) {
+                keys_from_desc(d, tok_w0, t, [&](uint32_t lo, uint32_t hi) {
+                    const uint64_t key = make_key(a, lo, hi);
+                    const uint32_t b1 = (uint32_t)sage_mix64(key) & (NB1 - 1);
+                    const uint32_t r = atomicAdd(&cnt[seg - s0][b1], 1u);
+                    rec[gbase[seg - s0][b1] + r] = key;
+                });
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Over-long windows (listed by k_describe): one global atomic per key, same two modes.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_key_partition_over(WalkArrays A, uint32_t n_tok, SegPlan S,
+                                                            const uint32_t* __restrict__ list,
+                                                            const uint32_t* __restrict__ n_list,
+                                                            unsigned long long* __restrict__ counters,
+                                                            unsigned long long* __restrict__ rec) {
+    const uint32_t n = *n_list;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const uint32_t t = list[i];
+        Walker w;
+        if (t >= n_tok || !w.init(A, t)) continue;
+        const uint32_t seg = find_segment(S, t);
+        const uint32_t a = w.a;
+        keys_from_walk(A, w, [&](uint32_t lo, uint32_t hi) {
+            const uint64_t key = make_key(a, lo, hi);
+            const uint32_t b1 = (uint32_t)sage_mix64(key) & (NB1 - 1);
+            if (MODE == 0) atomicAdd(&counters[(size_t)seg * NB1 + b1], 1ull);
+            else rec[atomicAdd(&counters[(size_t)seg * NB1 + b1], 1ull)] = key;
+        });
+    }
+}
+
+// ---- pass 3: one block per coarse bucket ---------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lds_set_insert(unsigned long long* set, uint64_t key, uint64_t h, uint32_t* flags) {
+    uint32_t s = (uint32_t)(h >> 32) & (SET_SLOTS - 1);
+    for (uint32_t probes = 0; probes < SET_SLOTS; ++probes) {
+        const unsigned long long old = atomicCAS(&set[s], (unsigned long long)SAGE_SET_EMPTY, (unsigned long long)key);
+        if (old == SAGE_SET_EMPTY) return ((uint32_t)(key >> 20) & SAGE_ID_MASK) == ((uint32_t)key & SAGE_ID_MASK) ? 1u : 2u;
+        if (old == key) return 0u;
+        s = (s + 1) & (SET_SLOTS - 1);
+    }
+    flags[FLAG_SET_OVERFLOW] = 1;
+    return 0u;
+}
+
+__global__ __launch_bounds__(256) void k_key_dedupe(const unsigned long long* __restrict__ bucket_off /* n_buckets+1 */,
+                                                    uint32_t n_buckets, const unsigned long long* __restrict__ rec_in,
+                                                    unsigned long long* __restrict__ rec_tmp,
+                                                    unsigned long long* __restrict__ stats, uint32_t* __restrict__ flags) {
+    __shared__ unsigned long long set[SET_SLOTS];
+    __shared__ unsigned int hist2[NB2_MAX];
+    __shared__ unsigned int offs2[NB2_MAX + 1];
+    __shared__ unsigned int wsum[4];
+    unsigned long long n_distinct = 0;
+    for (uint32_t bk = blockIdx.x; bk < n_buckets; bk += gridDim.x) {
+        const unsigned long long o0 = bucket_off[bk];
+        const uint32_t cnt = (uint32_t)(bucket_off[bk + 1] - o0);
+        if (cnt == 0) continue;
+        const unsigned long long* in = rec_in + o0;
+        unsigned long long* tmp = rec_tmp + o0;
+        uint32_t nb2 = 1;
+        while (nb2 < NB2_MAX && (uint64_t)nb2 * FINE_TARGET < cnt) nb2 <<= 1;
+        const unsigned long long* src = in;
+        __syncthreads();
+        if (nb2 > 1) {
+            // fine partition inside the block: histogram, exclusive scan, scatter into tmp
+            for (uint32_t i = threadIdx.x; i < nb2; i += 256) hist2[i] = 0;
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
+                const uint64_t h = sage_mix64(in[i]);
+                atomicAdd(&hist2[(uint32_t)(h >> 6) & (nb2 - 1)], 1u);
+            }
+            __syncthreads();
+            {   // exclusive scan of up to 256 counters by the 256 threads
+                const uint32_t v = threadIdx.x < nb2 ? hist2[threadIdx.x] : 0u;
+                uint32_t incl = v;
+                const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#pragma unroll
+                for (int dd = 1; dd < 64; dd <<= 1) {
+                    const uint32_t nn = __shfl_up(incl, dd, 64);
+                    if (lane >= (uint32_t)dd) incl += nn;
+                }
+                if (lane == 63) wsum[wave] = incl;
+                __syncthreads();
+                uint32_t wbase = 0;
+                for (uint32_t ww = 0; ww < wave; ++ww) wbase += wsum[ww];
+                if (threadIdx.x < nb2) { offs2[threadIdx.x] = wbase + incl - v; hist2[threadIdx.x] = wbase + incl - v; }
+                if (threadIdx.x == 0) offs2[nb2] = cnt;
+            }
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
+                const uint64_t key = in[i];
+                const uint64_t h = sage_mix64(key);
+                const uint32_t r = atomicAdd(&hist2[(uint32_t)(h >> 6) & (nb2 - 1)], 1u);
+                tmp[r] = key;
+            }
+            __threadfence_block();
+            __syncthreads();
+            src = tmp;
+        } else {
+            if (threadIdx.x == 0) { offs2[0] = 0; offs2[1] = cnt; }
+            __syncthreads();
+        }
+        for (uint32_t fb = 0; fb < nb2; ++fb) {
+            const uint32_t f0 = offs2[fb], fn = offs2[fb + 1] - f0;
+            if (fn == 0) continue;
+            const uint32_t passes = (fn + SET_FILL - 1) / SET_FILL;
+            for (uint32_t p = 0; p < passes; ++p) {
+                for (uint32_t i = threadIdx.x; i < SET_SLOTS; i += 256) set[i] = SAGE_SET_EMPTY;
+                __syncthreads();
+                for (uint32_t i = threadIdx.x; i < fn; i += 256) {
+                    const uint64_t key = src[f0 + i];
+                    const uint64_t h = sage_mix64(key);
+                    if (passes == 1 || ((uint32_t)(h >> 14) & 0x3FFFFu) % passes == p)
+                        n_distinct += lds_set_insert(set, key, h, flags);
+                }
+                __syncthreads();
+            }
+        }
+    }
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) n_distinct += __shfl_down(n_distinct, dd, 64);
+    if ((threadIdx.x & 63u) == 0 && n_distinct) atomicAdd(&stats[STAT_DISTINCT], n_distinct);
+}

@@ -43,6 +43,13 @@ def test_tokenize_golden(tag):
 
 
 def _check_step(eng, bounds, want_tokens, want_triples, want_losses, want_sizes, want_occ=None, abs_scale=None):
+    for mode in (0, 1):   # both distinct-count back ends: LDS partition/dedupe and HBM sets
+        eng.set_count_mode(mode)
+        _check_step_once(eng, bounds, want_tokens, want_triples, want_losses, want_sizes, want_occ, abs_scale)
+    eng.set_count_mode(0)
+
+
+def _check_step_once(eng, bounds, want_tokens, want_triples, want_losses, want_sizes, want_occ=None, abs_scale=None):
     loss, occ, tt, ttr, hist = eng.ablation_step(bounds)
     assert tt == want_tokens
     assert ttr == want_triples
@@ -159,3 +166,27 @@ def test_step_vs_oracle(style, max_len, dim):
         eng.set_embeddings(emb)
         _check_step(eng, segment_line_bounds(len(lines), W, flush=flush), tt, ttr, losses, sizes, want_occ=occs)
         eng.close()
+
+
+def test_long_windows_vs_oracle():
+    """Ablations into more pieces than a 64-byte descriptor holds (k up to 20) and never-rejoining ablations take
+    the streaming fallback; results must not change."""
+    from oracle import sage_oracle as orc
+    from sage_amd import synth
+    from sage_amd.parallel import pack_lines, segment_line_bounds
+    vocab = [bytes([i]) for i in range(256)] + [b"abcdefghijklmnop", b"qrstuvwxyzABCDEFGHIJ", b"ab", b"the ", b" cat",
+                                               b"pq", b"opq", b"mnopq"]
+    lines = [b"abcdefghijklmnop the cat abcdefghijklmnopq\n", b"qrstuvwxyzABCDEFGHIJ\n", b"x abcdefghijklmnop",
+             b"the qrstuvwxyzABCDEFGHIJ the abcdefghijklmnop cat\n", b"abcdefghijklmnopqrstuvwxyzABCDEFGHIJ the \n"] * 7
+    emb = synth.make_embeddings(len(vocab), 50, seed=2)
+    tok = orc.OracleTokenizer(vocab, 20)
+    occs = {}
+    losses, tt, ttr, sizes = orc.run_shard(tok, lines, emb, flush=9, occurrences=occs)
+    assert max(sizes) > 15
+    eng = _engine()
+    eng.set_vocab(vocab, None, 20)
+    flat, off = pack_lines(lines)
+    eng.set_corpus(flat, off)
+    eng.set_embeddings(emb)
+    _check_step(eng, segment_line_bounds(len(lines), 1, flush=9), tt, ttr, losses, sizes, want_occ=occs)
+    eng.close()
