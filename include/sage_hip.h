@@ -117,6 +117,9 @@ int sage_get_kernel_times(sage_ctx* ctx, double* out_ms /*[SAGE_K_NCLASSES]*/, i
 /* Tunables: scratch is sized for batches of at most `bytes` corpus bytes (default 256 MiB). */
 int sage_set_batch_bytes(sage_ctx* ctx, int64_t bytes);
 
+/* Matcher variant: 0 = persistent blocks with the 128 KiB presence filter in LDS (default), 1 = plain. */
+int sage_set_match_mode(sage_ctx* ctx, int mode);
+
 /* Distinct-key counting back end: 0 = hash partition + LDS dedupe (default), 1 = per-segment sets in HBM (the
  * fallback the library takes by itself if an LDS set ever overflows).  Results are identical. */
 int sage_set_count_mode(sage_ctx* ctx, int mode);

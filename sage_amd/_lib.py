@@ -65,6 +65,8 @@ def load():
     lib.sage_get_kernel_times.argtypes = [vp, pf64, pi64]
     lib.sage_set_batch_bytes.restype = C.c_int
     lib.sage_set_batch_bytes.argtypes = [vp, i64]
+    lib.sage_set_match_mode.restype = C.c_int
+    lib.sage_set_match_mode.argtypes = [vp, C.c_int]
     lib.sage_set_count_mode.restype = C.c_int
     lib.sage_set_count_mode.argtypes = [vp, C.c_int]
     lib.sage_get_step_stats.restype = C.c_int
@@ -76,7 +78,7 @@ def load():
 EXPORTED = ["sage_version", "sage_create", "sage_destroy", "sage_last_error", "sage_set_vocab", "sage_set_corpus",
             "sage_set_embeddings", "sage_tokenize", "sage_ablation_step", "sage_ablation_step_device",
             "sage_set_profiling", "sage_reset_kernel_times", "sage_get_kernel_times", "sage_set_batch_bytes",
-            "sage_set_count_mode", "sage_get_step_stats"]
+            "sage_set_match_mode", "sage_set_count_mode", "sage_get_step_stats"]
 
 
 class HipSage:
@@ -194,6 +196,9 @@ class HipSage:
 
     def set_batch_bytes(self, nbytes: int):
         self._check(self._lib.sage_set_batch_bytes(self._h, int(nbytes)))
+
+    def set_match_mode(self, mode: int):
+        self._check(self._lib.sage_set_match_mode(self._h, int(mode)))
 
     def set_count_mode(self, mode: int):
         self._check(self._lib.sage_set_count_mode(self._h, int(mode)))

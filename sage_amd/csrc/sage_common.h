@@ -30,6 +30,11 @@ SAGE_HD uint32_t sage_slot_make(uint32_t id, uint32_t len, uint32_t f) {
 }
 SAGE_HD uint32_t sage_slot_want(uint32_t len, uint32_t f) { return ((f >> 25) << 5) | (len - 1u); }
 
+// LDS presence filter of the matcher: 2^20 bits (128 KiB), two bit positions per key from its finalised hash.
+#define SAGE_BLOOM_BITS (1u << 20)
+SAGE_HD uint32_t sage_bloom_bit1(uint32_t f) { return (f * 0x9E3779B1u) >> 12; }
+SAGE_HD uint32_t sage_bloom_bit2(uint32_t f) { return ((f ^ (f >> 13)) * 0x85EBCA6Bu) >> 12; }
+
 SAGE_HD uint64_t sage_mix64(uint64_t k) {
     k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
     return k;

@@ -29,11 +29,13 @@ struct EventPair { hipEvent_t a, b; int cls; };
 
 struct sage_ctx {
     int device = 0;
+    int n_cu = 256;
     hipStream_t stream = nullptr;
     std::string err;
 
     // vocabulary
-    DevBuf buckets, keys, byte_id;
+    DevBuf buckets, keys, byte_id, bloom;
+    int match_mode = 0;  // 0 = LDS-filtered persistent matcher, 1 = plain matcher
     uint32_t bucket_mask = 0;
     int max_len = 0;
     int64_t max_id = -1;
@@ -152,7 +154,8 @@ int match_and_count(sage_ctx* c, int64_t line0, int64_t line1, uint64_t* out_tot
     if ((rc = ensure(c, c->tile_sums, (size_t)std::max(n_tiles, 1u) * 4))) return rc;
     if ((rc = ensure(c, c->grand_total, 8))) return rc;
 
-    VocabDev v{c->buckets.as<uint4>(), c->bucket_mask, c->keys.as<uint64_t>(), c->byte_id.as<uint32_t>(), c->max_len};
+    VocabDev v{c->buckets.as<uint4>(), c->bucket_mask, c->keys.as<uint64_t>(), c->byte_id.as<uint32_t>(),
+               c->bloom.as<uint32_t>(), c->max_len};
     if (nb) {
         Prof p(c, SAGE_K_MATCH);
         const uint32_t grid = cdiv(nb, 256);
@@ -160,7 +163,15 @@ int match_and_count(sage_ctx* c, int64_t line0, int64_t line1, uint64_t* out_tot
         const uint8_t* corpus = c->corpus.as<uint8_t>();
         const uint8_t* rem = c->rem.as<uint8_t>();
         uint2* M = c->M.as<uint2>();
-        switch (nw) {
+        if (c->match_mode == 0) {
+            const uint32_t pgrid = std::min<uint32_t>(cdiv(nb, 1024), (uint32_t)c->n_cu);
+            switch (nw) {
+            case 1: k_match_lds<1><<<pgrid, 1024, 0, c->stream>>>(corpus, rem, pos0, (uint32_t)nb, v, M); break;
+            case 2: k_match_lds<2><<<pgrid, 1024, 0, c->stream>>>(corpus, rem, pos0, (uint32_t)nb, v, M); break;
+            case 3: k_match_lds<3><<<pgrid, 1024, 0, c->stream>>>(corpus, rem, pos0, (uint32_t)nb, v, M); break;
+            default: k_match_lds<4><<<pgrid, 1024, 0, c->stream>>>(corpus, rem, pos0, (uint32_t)nb, v, M); break;
+            }
+        } else switch (nw) {
         case 1: k_match<1><<<grid, 256, 0, c->stream>>>(corpus, rem, pos0, (uint32_t)nb, v, M); break;
         case 2: k_match<2><<<grid, 256, 0, c->stream>>>(corpus, rem, pos0, (uint32_t)nb, v, M); break;
         case 3: k_match<3><<<grid, 256, 0, c->stream>>>(corpus, rem, pos0, (uint32_t)nb, v, M); break;
@@ -427,6 +438,10 @@ int sage_create(int device, sage_ctx** out_ctx) {
     if (hipSetDevice(device) != hipSuccess) return SAGE_E_HIP;
     sage_ctx* c = new sage_ctx();
     c->device = device;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
+    }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SAGE_E_HIP; }
     if (hipMalloc(&c->flags.p, FLAG_COUNT * 4) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return SAGE_E_HIP; }
     c->flags.cap = FLAG_COUNT * 4;
@@ -441,7 +456,7 @@ void sage_destroy(sage_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     collect_events(c);
     for (auto e : c->ev_free) (void)hipEventDestroy(e);
-    DevBuf* all[] = {&c->buckets, &c->keys, &c->byte_id, &c->corpus, &c->rem, &c->line_off, &c->emb, &c->M, &c->ntok,
+    DevBuf* all[] = {&c->buckets, &c->keys, &c->byte_id, &c->bloom, &c->corpus, &c->rem, &c->line_off, &c->emb, &c->M, &c->ntok,
                      &c->tokoff, &c->tile_sums, &c->grand_total, &c->tok_w0, &c->tok_pos, &c->set, &c->seg_line_rel,
                      &c->seg_tok_off, &c->set_base, &c->set_mask, &c->seg_pairs, &c->desc, &c->gcache, &c->over_list, &c->over_count, &c->hist1, &c->bucket_off, &c->rec_a, &c->rec_b, &c->ex_ids, &c->ex_starts, &c->ex_widths, &c->loss,
                      &c->occ, &c->hist, &c->stats, &c->flags};
@@ -469,6 +484,7 @@ int sage_set_vocab(sage_ctx* c, const uint8_t* key_bytes, const int64_t* key_off
     std::vector<uint64_t> keys((size_t)(max_id + 1) * 4, 0);
     const uint64_t nbuckets = pow2ceil(std::max<uint64_t>(16, (uint64_t)n_keys / 2));  // load factor <= 0.5
     std::vector<uint32_t> slots(nbuckets * 4, SAGE_SLOT_EMPTY);
+    std::vector<uint32_t> bloom(SAGE_BLOOM_BITS / 32, 0u);
     const uint32_t bmask = (uint32_t)(nbuckets - 1);
     for (int64_t i = 0; i < n_keys; ++i) {
         const uint32_t id = (uint32_t)(key_ids ? key_ids[i] : i);
@@ -479,6 +495,11 @@ int sage_set_vocab(sage_ctx* c, const uint8_t* key_bytes, const int64_t* key_off
         uint32_t h = SAGE_FNV_OFFSET;
         for (uint32_t j = 0; j < len; ++j) h = sage_fnv_step(h, k[j]);
         const uint32_t f = sage_mix32(h);
+        {
+            const uint32_t i1 = sage_bloom_bit1(f), i2 = sage_bloom_bit2(f);
+            bloom[i1 >> 5] |= 1u << (i1 & 31u);
+            bloom[i2 >> 5] |= 1u << (i2 & 31u);
+        }
         uint32_t b = f & bmask;
         for (;;) {
             uint32_t* s = &slots[(size_t)b * 4];
@@ -498,10 +519,12 @@ int sage_set_vocab(sage_ctx* c, const uint8_t* key_bytes, const int64_t* key_off
     if ((rc = ensure(c, c->buckets, slots.size() * 4))) return rc;
     if ((rc = ensure(c, c->keys, keys.size() * 8))) return rc;
     if ((rc = ensure(c, c->byte_id, 256 * 4))) return rc;
+    if ((rc = ensure(c, c->bloom, bloom.size() * 4))) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(c->buckets.p, slots.data(), slots.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->keys.p, keys.data(), keys.size() * 8, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->byte_id.p, byte_id.data(), 256 * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->bloom.p, bloom.data(), bloom.size() * 4, hipMemcpyHostToDevice));
     c->bucket_mask = bmask;
     c->max_len = max_len;
     c->max_id = max_id;
@@ -658,6 +681,12 @@ int sage_get_kernel_times(sage_ctx* c, double* out_ms, int64_t* out_launches) {
 int sage_set_batch_bytes(sage_ctx* c, int64_t bytes) {
     if (!c || bytes < 4096) return fail(c, SAGE_E_ARG, "batch_bytes must be at least 4096");
     c->batch_bytes = std::min<int64_t>(bytes, 0xF0000000ll);
+    return SAGE_OK;
+}
+
+int sage_set_match_mode(sage_ctx* c, int mode) {
+    if (!c || (mode != 0 && mode != 1)) return fail(c, SAGE_E_ARG, "match mode must be 0 or 1");
+    c->match_mode = mode;
     return SAGE_OK;
 }
 

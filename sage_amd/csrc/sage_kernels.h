@@ -10,6 +10,7 @@ struct VocabDev {
     uint32_t bucket_mask;     // nbuckets - 1
     const uint64_t* keys;     // [id][4] zero-padded key bytes, little-endian words
     const uint32_t* byte_id;  // id of each single-byte key
+    const uint32_t* bloom;    // SAGE_BLOOM_BITS-bit presence filter over (length, bytes), two bits per key
     int max_len;
 };
 
@@ -120,6 +121,181 @@ __global__ __launch_bounds__(256) void k_match(const uint8_t* __restrict__ corpu
         if (hit) { id2 = id1; len2 = len1; id1 = hid; len1 = (uint32_t)j; }
     }
     M[rel] = make_uint2(id1 | (len1 << 20), id2 | (len2 << 20));
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// K1 (filtered form): the same match, with a 128 KiB presence filter (2 bits per key) resident in LDS.  k_match is
+// bound by the L2 request rate of its 15 bucket probes per byte (measured: ~20 L2 requests per byte); the filter
+// turns most misses into two LDS reads (measured: ~5 L2 requests per byte).  Candidate lengths are probed in chunks
+// of 8 from the longest down: all bucket loads of a chunk are in flight together, then all key loads, so a wave
+// pays ~2 memory latencies per chunk instead of one per length; a chunk is skipped once two matches are known.
+// One persistent 1024-thread block per CU keeps the filter in LDS while it sweeps tiles of 1024 corpus bytes.
+// ----------------------------------------------------------------------------------------------------------
+template <int NW>
+__device__ __forceinline__ bool key_equal(const uint64_t (&W)[NW], const uint64_t* __restrict__ key, int j) {
+    bool same = true;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const int nb = j - 8 * w;
+        if (nb > 0) {
+            const uint64_t mask = nb >= 8 ? ~0ull : ((1ull << (8 * nb)) - 1ull);
+            same = same && ((W[w] & mask) == key[w]);
+        }
+    }
+    return same;
+}
+
+// exact serial probe of one length (any bucket chain length, any number of tag collisions)
+template <int NW>
+__device__ __forceinline__ bool probe_exact(const VocabDev& v, uint32_t b, uint32_t want, const uint64_t (&W)[NW], int j,
+                                            uint32_t& hid) {
+    for (;;) {
+        const uint4 s = v.buckets[b];
+        const uint32_t slot[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (slot[q] != SAGE_SLOT_EMPTY && (slot[q] >> 20) == want) {
+                const uint32_t cnd = slot[q] & SAGE_ID_MASK;
+                if (key_equal<NW>(W, v.keys + (size_t)cnd * 4, j)) { hid = cnd; return true; }
+            }
+        }
+        if (s.w == SAGE_SLOT_EMPTY) return false;
+        b = (b + 1u) & v.bucket_mask;
+    }
+}
+
+// Probes the candidate lengths JLO..JHI (at most 8) with all loads of a phase in flight together.
+// hitm gets bit (j-1) for every matching length, hid[j - JLO] its id.
+template <int NW, int JLO, int JHI, int ML>
+__device__ __forceinline__ void probe_chunk(const VocabDev& v, uint32_t cand, const uint32_t (&want)[ML + 1],
+                                            const uint32_t (&bidx)[ML + 1], const uint64_t (&W)[NW], uint32_t& hitm,
+                                            uint32_t (&hid)[8]) {
+    constexpr int N = JHI - JLO + 1;
+    uint4 bk[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        if ((cand >> (JLO + i - 1)) & 1u) bk[i] = v.buckets[bidx[JLO + i]];
+    uint32_t cid[N];
+    uint32_t have = 0, slow = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        cid[i] = 0;
+        if ((cand >> (JLO + i - 1)) & 1u) {
+            const uint32_t slot[4] = {bk[i].x, bk[i].y, bk[i].z, bk[i].w};
+            uint32_t nmatch = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (slot[q] != SAGE_SLOT_EMPTY && (slot[q] >> 20) == want[JLO + i]) { cid[i] = slot[q] & SAGE_ID_MASK; ++nmatch; }
+            if (nmatch == 1u) have |= 1u << i;
+            // two tag matches in one bucket, or a full bucket with no match: resolve exactly, one length at a time
+            if (nmatch > 1u || (nmatch == 0u && bk[i].w != SAGE_SLOT_EMPTY)) slow |= 1u << i;
+        }
+    }
+    uint64_t K[N][NW];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        if ((have >> i) & 1u) {
+            const uint64_t* key = v.keys + (size_t)cid[i] * 4;
+#pragma unroll
+            for (int w = 0; w < NW; ++w)
+                if (JLO + i - 8 * w > 0) K[i][w] = key[w];
+        }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        if ((have >> i) & 1u) {
+            if (key_equal<NW>(W, K[i], JLO + i)) { hitm |= 1u << (JLO + i - 1); hid[i] = cid[i]; }
+            else if (bk[i].w != SAGE_SLOT_EMPTY) slow |= 1u << i;   // tag false positive in a full bucket: keep looking
+        }
+    }
+    if (slow) {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            if ((slow >> i) & 1u) {
+                uint32_t id;
+                if (probe_exact<NW>(v, bidx[JLO + i], want[JLO + i], W, JLO + i, id)) { hitm |= 1u << (JLO + i - 1); hid[i] = id; }
+            }
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ corpus, const uint8_t* __restrict__ rem,
+                                                    int64_t pos0, uint32_t count, VocabDev v, uint2* __restrict__ M) {
+    constexpr int ML = 8 * NW;
+    constexpr int NDW = (1024 + ML + 8) / 4 + 1;
+    __shared__ uint32_t bloom[SAGE_BLOOM_BITS / 32];
+    __shared__ uint32_t text[NDW];
+    const uint32_t tid = threadIdx.x;
+    {
+        const uint4* src4 = reinterpret_cast<const uint4*>(v.bloom);
+        uint4* dst4 = reinterpret_cast<uint4*>(bloom);
+        for (uint32_t i = tid; i < SAGE_BLOOM_BITS / 128; i += 1024) dst4[i] = src4[i];
+    }
+    const uint32_t n_tiles = (count + 1023u) / 1024u;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t blk0 = pos0 + (int64_t)tile * 1024;
+        const int64_t a0 = blk0 & ~(int64_t)3;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(corpus + a0);
+        __syncthreads();
+        for (uint32_t i = tid; i < NDW; i += 1024) text[i] = src[i];
+        __syncthreads();
+        const uint32_t rel = tile * 1024u + tid;
+        if (rel >= count) continue;
+        const uint32_t o = (uint32_t)(blk0 - a0) + tid;
+        const uint32_t wi = o >> 2, sh = (o & 3u) * 8u;
+        uint32_t T[2 * NW];
+        {
+            uint32_t d[2 * NW + 1];
+#pragma unroll
+            for (int i = 0; i <= 2 * NW; ++i) d[i] = text[wi + i];
+#pragma unroll
+            for (int i = 0; i < 2 * NW; ++i) T[i] = __funnelshift_r(d[i], d[i + 1], sh);
+        }
+        const int lim = min((int)rem[blk0 + tid], v.max_len);
+        uint32_t want[ML + 1];
+        uint32_t bidx[ML + 1];
+        uint32_t cand = 0;
+        uint32_t h = sage_fnv_step(SAGE_FNV_OFFSET, T[0] & 0xFFu);
+#pragma unroll
+        for (int j = 2; j <= ML; ++j) {
+            const uint32_t b = (T[(j - 1) >> 2] >> (8 * ((j - 1) & 3))) & 0xFFu;
+            h = sage_fnv_step(h, b);
+            const uint32_t f = sage_mix32(h);
+            want[j] = sage_slot_want(j, f);
+            bidx[j] = f & v.bucket_mask;
+            const uint32_t i1 = sage_bloom_bit1(f), i2 = sage_bloom_bit2(f);
+            const bool maybe = j <= lim && ((bloom[i1 >> 5] >> (i1 & 31u)) & (bloom[i2 >> 5] >> (i2 & 31u)) & 1u);
+            if (maybe) cand |= 1u << (j - 1);
+        }
+        uint64_t W[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) W[w] = (uint64_t)T[2 * w] | ((uint64_t)T[2 * w + 1] << 32);
+        uint32_t hitm = 0;
+        uint32_t hid[NW][8];
+        // chunks from the longest lengths down; a chunk is skipped when two matches are already known
+        if constexpr (NW >= 4) {
+            if (cand >> 24) probe_chunk<NW, 25, 32, ML>(v, cand, want, bidx, W, hitm, hid[3]);
+        }
+        if constexpr (NW >= 3) {
+            if (((cand >> 16) & 0xFFu) && __popc(hitm) < 2) probe_chunk<NW, 17, 24, ML>(v, cand, want, bidx, W, hitm, hid[2]);
+        }
+        if constexpr (NW >= 2) {
+            if (((cand >> 8) & 0xFFu) && __popc(hitm) < 2) probe_chunk<NW, 9, 16, ML>(v, cand, want, bidx, W, hitm, hid[1]);
+        }
+        if ((cand & 0xFFu) && __popc(hitm) < 2) probe_chunk<NW, 2, 8, ML>(v, cand, want, bidx, W, hitm, hid[0]);
+        // the two longest matches (the single byte always matches)
+        const uint32_t idb = v.byte_id[T[0] & 0xFFu];
+        uint32_t id1 = idb, len1 = 1, id2 = 0, len2 = 0, hits = 0;
+#pragma unroll
+        for (int j = ML; j >= 2; --j) {
+            if (hits < 2u && ((hitm >> (j - 1)) & 1u)) {
+                const uint32_t id = hid[(j - 1) / 8 >= NW ? NW - 1 : (j <= 8 ? 0 : (j - 1) / 8)][j <= 8 ? j - 2 : (j - 1) % 8];
+                if (hits == 0u) { id1 = id; len1 = (uint32_t)j; } else { id2 = id; len2 = (uint32_t)j; }
+                ++hits;
+            }
+        }
+        if (hits == 1u) { id2 = idb; len2 = 1; }
+        M[rel] = make_uint2(id1 | (len1 << 20), id2 | (len2 << 20));
+    }
 }
 
 // ----------------------------------------------------------------------------------------------------------

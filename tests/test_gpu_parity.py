@@ -34,6 +34,11 @@ def test_tokenize_golden(tag):
     assert ids.tolist() == g["ids"].tolist()
     assert starts.tolist() == g["starts"].tolist()
     assert widths.tolist() == g["widths"].tolist()
+    # the plain (unfiltered) matcher gives the same answer
+    eng.set_match_mode(1)
+    ids1, starts1, widths1, counts1 = eng.tokenize(0, len(lines))
+    assert ids1.tolist() == ids.tolist() and widths1.tolist() == widths.tolist() and counts1.tolist() == counts.tolist()
+    eng.set_match_mode(0)
     # small batches must give the same answer (batch seams)
     eng.set_batch_bytes(4096)
     ids2, starts2, widths2, counts2 = eng.tokenize(0, len(lines))
