@@ -19,8 +19,8 @@
 // incrementally: h(j) = fnv_step(h(j-1), byte[j-1]).
 #define SAGE_FNV_OFFSET 0x811C9DC5u
 SAGE_HD uint32_t sage_fnv_step(uint32_t h, uint32_t b) { return (h ^ b) * 16777619u; }
-SAGE_HD uint32_t sage_mix32(uint32_t x) {
-    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+SAGE_HD uint32_t sage_mix32(uint32_t x) {   // one multiply: v_mul_lo_u32 is quarter rate on gfx950
+    x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 13;
     return x;
 }
 // A vocab-table slot: id[0:20) | (len-1)[20:25) | tag[25:32).  A bucket is 4 slots (one 16-byte load), filled in
@@ -32,8 +32,8 @@ SAGE_HD uint32_t sage_slot_want(uint32_t len, uint32_t f) { return ((f >> 25) <<
 
 // LDS presence filter of the matcher: 2^20 bits (128 KiB), two bit positions per key from its finalised hash.
 #define SAGE_BLOOM_BITS (1u << 20)
-SAGE_HD uint32_t sage_bloom_bit1(uint32_t f) { return (f * 0x9E3779B1u) >> 12; }
-SAGE_HD uint32_t sage_bloom_bit2(uint32_t f) { return ((f ^ (f >> 13)) * 0x85EBCA6Bu) >> 12; }
+SAGE_HD uint32_t sage_bloom_bit1(uint32_t f) { return f >> 12; }
+SAGE_HD uint32_t sage_bloom_bit2(uint32_t f) { return (((f << 9) | (f >> 23)) ^ (f >> 5)) & (SAGE_BLOOM_BITS - 1u); }
 
 SAGE_HD uint64_t sage_mix64(uint64_t k) {
     k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;

@@ -164,7 +164,9 @@ __device__ __forceinline__ bool probe_exact(const VocabDev& v, uint32_t b, uint3
     }
 }
 
-// Probes the candidate lengths JLO..JHI (at most 8) with all loads of a phase in flight together.
+// Probes the candidate lengths JLO..JHI (at most 8) with all loads of a phase in flight together.  Branch-free:
+// a lane that has no candidate at a length loads bucket 0 / key 0 instead (one shared cache line), which costs
+// far less than the exec-mask bookkeeping of a divergent branch per length.
 // hitm gets bit (j-1) for every matching length, hid[j - JLO] its id.
 template <int NW, int JLO, int JHI, int ML>
 __device__ __forceinline__ void probe_chunk(const VocabDev& v, uint32_t cand, const uint32_t (&want)[ML + 1],
@@ -173,39 +175,39 @@ __device__ __forceinline__ void probe_chunk(const VocabDev& v, uint32_t cand, co
     constexpr int N = JHI - JLO + 1;
     uint4 bk[N];
 #pragma unroll
-    for (int i = 0; i < N; ++i)
-        if ((cand >> (JLO + i - 1)) & 1u) bk[i] = v.buckets[bidx[JLO + i]];
+    for (int i = 0; i < N; ++i) bk[i] = v.buckets[((cand >> (JLO + i - 1)) & 1u) ? bidx[JLO + i] : 0u];
     uint32_t cid[N];
     uint32_t have = 0, slow = 0;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        cid[i] = 0;
-        if ((cand >> (JLO + i - 1)) & 1u) {
-            const uint32_t slot[4] = {bk[i].x, bk[i].y, bk[i].z, bk[i].w};
-            uint32_t nmatch = 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (slot[q] != SAGE_SLOT_EMPTY && (slot[q] >> 20) == want[JLO + i]) { cid[i] = slot[q] & SAGE_ID_MASK; ++nmatch; }
-            if (nmatch == 1u) have |= 1u << i;
-            // two tag matches in one bucket, or a full bucket with no match: resolve exactly, one length at a time
-            if (nmatch > 1u || (nmatch == 0u && bk[i].w != SAGE_SLOT_EMPTY)) slow |= 1u << i;
-        }
+        const uint32_t on = (cand >> (JLO + i - 1)) & 1u;
+        const uint32_t w = want[JLO + i];
+        const uint32_t m0 = (bk[i].x != SAGE_SLOT_EMPTY) & ((bk[i].x >> 20) == w);
+        const uint32_t m1 = (bk[i].y != SAGE_SLOT_EMPTY) & ((bk[i].y >> 20) == w);
+        const uint32_t m2 = (bk[i].z != SAGE_SLOT_EMPTY) & ((bk[i].z >> 20) == w);
+        const uint32_t m3 = (bk[i].w != SAGE_SLOT_EMPTY) & ((bk[i].w >> 20) == w);
+        const uint32_t nmatch = m0 + m1 + m2 + m3;
+        cid[i] = (m0 ? bk[i].x : (m1 ? bk[i].y : (m2 ? bk[i].z : bk[i].w))) & SAGE_ID_MASK;
+        const uint32_t full = bk[i].w != SAGE_SLOT_EMPTY;
+        have |= (on & (nmatch == 1u)) << i;
+        // two tag matches in one bucket, or a full bucket with no match: resolve exactly, one length at a time
+        slow |= (on & ((nmatch > 1u) | ((nmatch == 0u) & full))) << i;
     }
     uint64_t K[N][NW];
 #pragma unroll
-    for (int i = 0; i < N; ++i)
-        if ((have >> i) & 1u) {
-            const uint64_t* key = v.keys + (size_t)cid[i] * 4;
+    for (int i = 0; i < N; ++i) {
+        const uint64_t* key = v.keys + (size_t)(((have >> i) & 1u) ? cid[i] : 0u) * 4;
 #pragma unroll
-            for (int w = 0; w < NW; ++w)
-                if (JLO + i - 8 * w > 0) K[i][w] = key[w];
-        }
+        for (int w = 0; w < NW; ++w)
+            if (JLO + i - 8 * w > 0) K[i][w] = key[w];
+    }
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        if ((have >> i) & 1u) {
-            if (key_equal<NW>(W, K[i], JLO + i)) { hitm |= 1u << (JLO + i - 1); hid[i] = cid[i]; }
-            else if (bk[i].w != SAGE_SLOT_EMPTY) slow |= 1u << i;   // tag false positive in a full bucket: keep looking
-        }
+        const uint32_t hv = (have >> i) & 1u;
+        const uint32_t eq = key_equal<NW>(W, K[i], JLO + i) ? 1u : 0u;
+        hitm |= (hv & eq) << (JLO + i - 1);
+        hid[i] = cid[i];
+        slow |= (hv & (eq ^ 1u) & (uint32_t)(bk[i].w != SAGE_SLOT_EMPTY)) << i;  // tag false positive in a full bucket
     }
     if (slow) {
 #pragma unroll
@@ -272,16 +274,23 @@ __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ 
         uint32_t hitm = 0;
         uint32_t hid[NW][8];
         // chunks from the longest lengths down; a chunk is skipped when two matches are already known
+        // a chunk runs if ANY lane of the wave still needs it (wave-uniform branch); lanes that do not take part in it
+        // are masked through their candidate bits, not through EXEC
         if constexpr (NW >= 4) {
-            if (cand >> 24) probe_chunk<NW, 25, 32, ML>(v, cand, want, bidx, W, hitm, hid[3]);
+            if (__any((cand >> 24) != 0u)) probe_chunk<NW, 25, 32, ML>(v, cand, want, bidx, W, hitm, hid[3]);
         }
         if constexpr (NW >= 3) {
-            if (((cand >> 16) & 0xFFu) && __popc(hitm) < 2) probe_chunk<NW, 17, 24, ML>(v, cand, want, bidx, W, hitm, hid[2]);
+            const uint32_t c3 = __popc(hitm) < 2 ? cand : 0u;
+            if (__any(((c3 >> 16) & 0xFFu) != 0u)) probe_chunk<NW, 17, 24, ML>(v, c3, want, bidx, W, hitm, hid[2]);
         }
         if constexpr (NW >= 2) {
-            if (((cand >> 8) & 0xFFu) && __popc(hitm) < 2) probe_chunk<NW, 9, 16, ML>(v, cand, want, bidx, W, hitm, hid[1]);
+            const uint32_t c2 = __popc(hitm) < 2 ? cand : 0u;
+            if (__any(((c2 >> 8) & 0xFFu) != 0u)) probe_chunk<NW, 9, 16, ML>(v, c2, want, bidx, W, hitm, hid[1]);
         }
-        if ((cand & 0xFFu) && __popc(hitm) < 2) probe_chunk<NW, 2, 8, ML>(v, cand, want, bidx, W, hitm, hid[0]);
+        {
+            const uint32_t c1 = __popc(hitm) < 2 ? cand : 0u;
+            if (__any((c1 & 0xFFu) != 0u)) probe_chunk<NW, 2, 8, ML>(v, c1, want, bidx, W, hitm, hid[0]);
+        }
         // the two longest matches (the single byte always matches)
         const uint32_t idb = v.byte_id[T[0] & 0xFFu];
         uint32_t id1 = idb, len1 = 1, id2 = 0, len2 = 0, hits = 0;
