@@ -169,6 +169,7 @@ def main():
             "score": st["rows"] * args.dim * 8,
             "describe": st["corpus_bytes"] * 8 + tokens_local * (8 + 64),
             "pairs": tokens_local * (args.dim * 8 + 16),
+            "logsig": st["pairs"] * 8 + st["occurrences"] * 64,
         }
         dom = max(per_kernel_bytes, key=lambda k: kt[k][0])
         dom_ms, dom_n = kt[dom]

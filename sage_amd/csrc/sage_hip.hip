@@ -54,7 +54,9 @@ struct sage_ctx {
     bool have_emb = false;
 
     // scratch (grow-only; nothing is allocated in the steady state)
-    DevBuf M, ntok, tokoff, tile_sums, grand_total, tok_w0, tok_pos, set, seg_line_rel, seg_tok_off, set_base, set_mask, seg_pairs, desc, gcache, over_list, over_count, hist1, bucket_off, rec_a, rec_b;
+    DevBuf M, ntok, tokoff, tile_sums, grand_total, tok_w0, tok_pos, set, seg_line_rel, seg_tok_off, set_base, set_mask, seg_pairs, desc, gcache, hist1, bucket_off, rec_a, rec_b,
+        nocc, occoff, occ_tok, np_ab, dot_off, dots, pool, pool_cursor;
+    int pool_factor = 8;  // id-pool words per occurrence (grown on overflow)
     int count_mode = 0;  // 0 = partition + LDS dedupe (v2), 1 = per-segment HBM sets (v1, also the overflow fallback)
     DevBuf ex_ids, ex_starts, ex_widths;
     DevBuf loss, occ, hist, stats, flags;
@@ -140,7 +142,20 @@ uint64_t pow2ceil(uint64_t x) {
 
 inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
-// K1 + K2a(count) + scan over lines [line0, line1): fills M, ntok, tokoff; returns the token total.
+// exclusive scan of n u32 values: out has n+1 entries, *total (device u64) gets the grand total
+int scan_u32(sage_ctx* c, const uint32_t* in, uint32_t n, uint32_t* out, uint64_t* d_total) {
+    const uint32_t n_tiles = std::max(1u, cdiv(n, SCAN_TILE));
+    int rc;
+    if ((rc = ensure(c, c->tile_sums, (size_t)n_tiles * 4))) return rc;
+    Prof p(c, SAGE_K_SCAN);
+    k_scan_tile_sums<<<n_tiles, 256, 0, c->stream>>>(in, n, c->tile_sums.as<uint32_t>());
+    k_scan_top<<<1, 256, 0, c->stream>>>(c->tile_sums.as<uint32_t>(), n_tiles, d_total);
+    k_scan_apply<<<n_tiles, 256, 0, c->stream>>>(in, n, c->tile_sums.as<uint32_t>(), out);
+    return SAGE_OK;
+}
+
+// K1 + K2a(count) + scans over lines [line0, line1): fills M, ntok/tokoff and nocc/occoff;
+// grand_total[0] = tokens, grand_total[1] = ablated occurrences (device).  out_total (optional) syncs.
 int match_and_count(sage_ctx* c, int64_t line0, int64_t line1, uint64_t* out_total) {
     const int64_t pos0 = c->h_line_off[line0];
     const uint64_t nb = (uint64_t)(c->h_line_off[line1] - pos0);
@@ -149,10 +164,10 @@ int match_and_count(sage_ctx* c, int64_t line0, int64_t line1, uint64_t* out_tot
     int rc;
     if ((rc = ensure(c, c->M, std::max<uint64_t>(nb, 1) * sizeof(uint2)))) return rc;
     if ((rc = ensure(c, c->ntok, (size_t)nl * 4))) return rc;
+    if ((rc = ensure(c, c->nocc, (size_t)nl * 4))) return rc;
     if ((rc = ensure(c, c->tokoff, ((size_t)nl + 1) * 4))) return rc;
-    const uint32_t n_tiles = cdiv(nl, SCAN_TILE);
-    if ((rc = ensure(c, c->tile_sums, (size_t)std::max(n_tiles, 1u) * 4))) return rc;
-    if ((rc = ensure(c, c->grand_total, 8))) return rc;
+    if ((rc = ensure(c, c->occoff, ((size_t)nl + 1) * 4))) return rc;
+    if ((rc = ensure(c, c->grand_total, 16))) return rc;
 
     VocabDev v{c->buckets.as<uint4>(), c->bucket_mask, c->keys.as<uint64_t>(), c->byte_id.as<uint32_t>(),
                c->bloom.as<uint32_t>(), c->max_len};
@@ -182,15 +197,10 @@ int match_and_count(sage_ctx* c, int64_t line0, int64_t line1, uint64_t* out_tot
         Prof p(c, SAGE_K_WALK);
         k_walk_count<<<cdiv(nl, 256), 256, 0, c->stream>>>(c->line_off.as<int64_t>(), line0, nl, pos0,
                                                             c->M.as<uint2>(), c->ntok.as<uint32_t>(),
-                                                            c->flags.as<uint32_t>());
+                                                            c->nocc.as<uint32_t>(), c->flags.as<uint32_t>());
     }
-    {
-        Prof p(c, SAGE_K_SCAN);
-        k_scan_tile_sums<<<n_tiles, 256, 0, c->stream>>>(c->ntok.as<uint32_t>(), nl, c->tile_sums.as<uint32_t>());
-        k_scan_top<<<1, 256, 0, c->stream>>>(c->tile_sums.as<uint32_t>(), n_tiles, c->grand_total.as<uint64_t>());
-        k_scan_apply<<<n_tiles, 256, 0, c->stream>>>(c->ntok.as<uint32_t>(), nl, c->tile_sums.as<uint32_t>(),
-                                                     c->tokoff.as<uint32_t>());
-    }
+    if ((rc = scan_u32(c, c->ntok.as<uint32_t>(), nl, c->tokoff.as<uint32_t>(), c->grand_total.as<uint64_t>()))) return rc;
+    if ((rc = scan_u32(c, c->nocc.as<uint32_t>(), nl, c->occoff.as<uint32_t>(), c->grand_total.as<uint64_t>() + 1))) return rc;
     HIP_TRY(c, hipGetLastError());
     if (out_total) {
         uint64_t tot = 0;
@@ -210,25 +220,35 @@ int check_ready(sage_ctx* c, bool need_emb) {
     return SAGE_OK;
 }
 
+// padded row width the score kernels are instantiated for
+int padded_dim(int dim) {
+    const int opts[] = {32, 64, 128, 256, 384, 512};
+    for (int o : opts) if (dim <= o) return o;
+    return 0;
+}
+
 template <int G, int EPL>
-void launch_score(sage_ctx* c, const WalkArrays& A, uint32_t n_tok, bool have_over) {
+void launch_score(sage_ctx* c, const uint32_t* tok_w0, uint32_t n_tok, uint32_t n_occ) {
     const uint32_t gpb = 256 / G;
     {
         Prof p(c, SAGE_K_PAIRS);
         const uint32_t grid = std::min<uint32_t>(cdiv(cdiv(n_tok, 4), gpb), 256u * 16u);
-        k_pair_cache<G, EPL><<<grid, 256, 0, c->stream>>>(A.tok_w0, n_tok, c->emb.as<double>(), (uint32_t)c->emb_rows,
+        k_pair_cache<G, EPL><<<grid, 256, 0, c->stream>>>(tok_w0, n_tok, c->emb.as<double>(), (uint32_t)c->emb_rows,
                                                           (uint32_t)c->dp, c->gcache.as<double2>(), c->flags.as<uint32_t>());
     }
     {
         Prof p(c, SAGE_K_SCORE);
-        const uint32_t grid = std::min<uint32_t>(cdiv(n_tok, 256), 256u * 8u);
-        k_score_desc<G, EPL><<<grid, 256, 0, c->stream>>>(c->desc.as<uint4>(), A.tok_w0, n_tok, c->emb.as<double>(),
-                                                          (uint32_t)c->emb_rows, (uint32_t)c->dp, c->gcache.as<double2>(),
-                                                          c->loss.as<double>(), c->flags.as<uint32_t>());
-        if (have_over)  // windows longer than a descriptor: the streaming walker scores them
-            k_score<G, EPL><<<64, 256, 0, c->stream>>>(A, n_tok, c->emb.as<double>(), (uint32_t)c->emb_rows, (uint32_t)c->dp,
-                                                       c->loss.as<double>(), c->flags.as<uint32_t>(),
-                                                       c->over_list.as<uint32_t>(), c->over_count.as<uint32_t>());
+        const uint32_t grid = std::min<uint32_t>(cdiv(n_occ, gpb), (uint32_t)c->n_cu * 4u);
+        k_dots<G, EPL><<<grid, 256, 0, c->stream>>>(c->desc.as<uint4>(), c->pool.as<uint32_t>(), n_occ,
+                                                    c->dot_off.as<uint32_t>(), c->emb.as<double>(), (uint32_t)c->emb_rows,
+                                                    (uint32_t)c->dp, c->dots.as<double>(), c->flags.as<uint32_t>());
+    }
+    {
+        Prof p(c, SAGE_K_LOGSIG);
+        const uint32_t grid = std::min<uint32_t>(cdiv(n_occ, 32), 256u * 8u);
+        k_logsig<<<grid, 256, 0, c->stream>>>(c->desc.as<uint4>(), c->occ_tok.as<uint32_t>(), tok_w0, n_occ,
+                                              c->dot_off.as<uint32_t>(), c->dots.as<double>(), c->gcache.as<double2>(),
+                                              c->loss.as<double>());
     }
 }
 
@@ -248,6 +268,7 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
     if ((rc = ensure(c, c->occ, (size_t)vsize * 8))) return rc;
     if ((rc = ensure(c, c->hist, (size_t)hist_len * 8))) return rc;
     if ((rc = ensure(c, c->stats, STAT_COUNT * 8))) return rc;
+    if ((rc = ensure(c, c->pool_cursor, 4))) return rc;
 
     for (int attempt = 0;; ++attempt) {
         HIP_TRY(c, hipMemsetAsync(c->loss.p, 0, (size_t)vsize * 8, c->stream));
@@ -255,7 +276,7 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
         HIP_TRY(c, hipMemsetAsync(c->hist.p, 0, (size_t)hist_len * 8, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->stats.p, 0, STAT_COUNT * 8, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->flags.p, 0, FLAG_COUNT * 4, c->stream));
-        uint64_t total_tokens = 0, total_bytes = 0;
+        uint64_t total_tokens = 0, total_bytes = 0, total_occ = 0;
 
         int64_t sa = 0;
         while (sa < n_seg) {
@@ -266,11 +287,12 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
             const uint32_t nsb = (uint32_t)(sb - sa);
             if (line1 == line0) { sa = sb; continue; }
             const int64_t pos0 = c->h_line_off[line0];
+            const uint32_t nl = (uint32_t)(line1 - line0);
             total_bytes += (uint64_t)(c->h_line_off[line1] - pos0);
 
             if ((rc = match_and_count(c, line0, line1, nullptr))) return rc;
 
-            // token offset of every segment start
+            // token offset of every segment start; totals of the batch
             std::vector<uint32_t> rel(nsb + 1);
             for (uint32_t s = 0; s <= nsb; ++s) rel[s] = (uint32_t)(bounds[sa + s] - line0);
             if ((rc = ensure(c, c->seg_line_rel, (size_t)(nsb + 1) * 4))) return rc;
@@ -278,42 +300,53 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
             HIP_TRY(c, hipMemcpyAsync(c->seg_line_rel.p, rel.data(), (size_t)(nsb + 1) * 4, hipMemcpyHostToDevice, c->stream));
             k_gather_u32<<<cdiv(nsb + 1, 256), 256, 0, c->stream>>>(c->tokoff.as<uint32_t>(), c->seg_line_rel.as<uint32_t>(),
                                                                     nsb + 1, c->seg_tok_off.as<uint32_t>());
-            std::vector<uint32_t> seg_tok(nsb + 1);
-            HIP_TRY(c, hipMemcpyAsync(seg_tok.data(), c->seg_tok_off.p, (size_t)(nsb + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+            uint64_t gt[2] = {0, 0};
+            HIP_TRY(c, hipMemcpyAsync(gt, c->grand_total.p, 16, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
-            const uint32_t n_tok = seg_tok[nsb];
+            if (gt[0] >= 0xFFFFFF00ull) return fail(c, SAGE_E_LIMIT, "a batch must stay under 2^32 tokens");
+            const uint32_t n_tok = (uint32_t)gt[0], n_occ = (uint32_t)gt[1];
             total_tokens += n_tok;
+            total_occ += n_occ;
             if (n_tok == 0) { sa = sb; continue; }
 
             if ((rc = ensure(c, c->tok_w0, (size_t)n_tok * 4))) return rc;
             if ((rc = ensure(c, c->tok_pos, (size_t)n_tok * 4))) return rc;
-            const uint32_t nl = (uint32_t)(line1 - line0);
+            if ((rc = ensure(c, c->occ_tok, (size_t)std::max(n_occ, 1u) * 4))) return rc;
             {
                 Prof p(c, SAGE_K_WALK);
                 k_walk_write<false><<<cdiv(nl, 256), 256, 0, c->stream>>>(
                     c->line_off.as<int64_t>(), line0, nl, pos0, c->M.as<uint2>(), c->tokoff.as<uint32_t>(),
-                    c->tok_w0.as<uint32_t>(), c->tok_pos.as<uint32_t>(), nullptr, nullptr, nullptr);
+                    c->occoff.as<uint32_t>(), c->tok_w0.as<uint32_t>(), c->tok_pos.as<uint32_t>(),
+                    c->occ_tok.as<uint32_t>(), nullptr, nullptr, nullptr);
             }
+            if (n_occ == 0) { HIP_TRY(c, hipGetLastError()); sa = sb; continue; }
             WalkArrays A{c->M.as<uint2>(), c->rem.as<uint8_t>() + pos0, c->tok_w0.as<uint32_t>(), c->tok_pos.as<uint32_t>()};
             if ((rc = ensure(c, c->set_base, (size_t)nsb * 8))) return rc;
             if ((rc = ensure(c, c->set_mask, (size_t)nsb * 8))) return rc;
             if ((rc = ensure(c, c->seg_pairs, (size_t)nsb * 8))) return rc;
-            if ((rc = ensure(c, c->desc, (size_t)n_tok * SAGE_DESC_WORDS * 4))) return rc;
+            if ((rc = ensure(c, c->desc, (size_t)n_occ * SAGE_DESC_WORDS * 4))) return rc;
             if ((rc = ensure(c, c->gcache, (size_t)n_tok * 16))) return rc;
-            if ((rc = ensure(c, c->over_list, (size_t)n_tok * 4))) return rc;
-            if ((rc = ensure(c, c->over_count, 4))) return rc;
+            if ((rc = ensure(c, c->np_ab, (size_t)n_occ * 4))) return rc;
+            if ((rc = ensure(c, c->dot_off, ((size_t)n_occ + 1) * 4))) return rc;
+            const uint64_t pool_cap = std::min<uint64_t>((uint64_t)n_occ * c->pool_factor + 1024, 0xFFFFFF00ull);
+            if ((rc = ensure(c, c->pool, pool_cap * 4))) return rc;
             HIP_TRY(c, hipMemsetAsync(c->seg_pairs.p, 0, (size_t)nsb * 8, c->stream));
-            HIP_TRY(c, hipMemsetAsync(c->over_count.p, 0, 4, c->stream));
+            HIP_TRY(c, hipMemsetAsync(c->pool_cursor.p, 0, 4, c->stream));
             SegPlan S{c->seg_tok_off.as<uint32_t>(), c->set_base.as<uint64_t>(), c->set_mask.as<uint64_t>(), nsb};
-            const uint32_t cgrid = std::min<uint32_t>(cdiv(n_tok, 256), 256u * 16u);
+            const uint32_t cgrid = std::min<uint32_t>(cdiv(n_occ, 256), 256u * 16u);
             {
                 Prof p(c, SAGE_K_DESCRIBE);
                 k_describe<<<cgrid, 256, 0, c->stream>>>(
-                    A, n_tok, S, c->desc.as<uint4>(), c->seg_pairs.as<unsigned long long>(),
-                    c->occ.as<unsigned long long>(), c->hist.as<unsigned long long>(), (uint32_t)hist_len,
-                    c->stats.as<unsigned long long>(), c->over_list.as<uint32_t>(), c->over_count.as<uint32_t>());
+                    A, c->occ_tok.as<uint32_t>(), n_occ, S, c->desc.as<uint4>(), c->np_ab.as<uint32_t>(),
+                    c->pool.as<uint32_t>(), c->pool_cursor.as<uint32_t>(), (uint32_t)pool_cap,
+                    c->seg_pairs.as<unsigned long long>(), c->occ.as<unsigned long long>(),
+                    c->hist.as<unsigned long long>(), (uint32_t)hist_len, c->stats.as<unsigned long long>(),
+                    c->flags.as<uint32_t>());
             }
-            uint32_t n_over = 0;
+            // offsets of every occurrence's ablated-window dots; grand_total[1] is reused for the dot total
+            if ((rc = scan_u32(c, c->np_ab.as<uint32_t>(), n_occ, c->dot_off.as<uint32_t>(), c->grand_total.as<uint64_t>() + 1))) return rc;
+
+            uint64_t n_dots = 0;
             if (c->count_mode == 0) {
                 // ---- v2: hash-partition the key stream, dedupe each bucket in LDS ----
                 const size_t nbk = (size_t)nsb * NB1;
@@ -322,15 +355,13 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
                 HIP_TRY(c, hipMemsetAsync(c->hist1.p, 0, nbk * 8, c->stream));
                 {
                     Prof p(c, SAGE_K_COUNT);
-                    k_key_partition<0><<<cgrid, 256, 0, c->stream>>>(c->desc.as<uint4>(), A.tok_w0, n_tok, S,
+                    k_key_partition<0><<<cgrid, 256, 0, c->stream>>>(c->desc.as<uint4>(), c->pool.as<uint32_t>(),
+                                                                     c->occ_tok.as<uint32_t>(), A.tok_w0, n_occ, S,
                                                                      c->hist1.as<unsigned long long>(), nullptr);
-                    k_key_partition_over<0><<<64, 256, 0, c->stream>>>(A, n_tok, S, c->over_list.as<uint32_t>(),
-                                                                       c->over_count.as<uint32_t>(),
-                                                                       c->hist1.as<unsigned long long>(), nullptr);
                 }
                 std::vector<uint64_t> h1(nbk), boff(nbk + 1);
                 HIP_TRY(c, hipMemcpyAsync(h1.data(), c->hist1.p, nbk * 8, hipMemcpyDeviceToHost, c->stream));
-                HIP_TRY(c, hipMemcpyAsync(&n_over, c->over_count.p, 4, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipMemcpyAsync(&n_dots, c->grand_total.as<uint64_t>() + 1, 8, hipMemcpyDeviceToHost, c->stream));
                 HIP_TRY(c, hipStreamSynchronize(c->stream));
                 uint64_t total = 0;
                 for (size_t i = 0; i < nbk; ++i) { boff[i] = total; total += h1[i]; }
@@ -341,13 +372,10 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
                 HIP_TRY(c, hipMemcpyAsync(c->hist1.p, boff.data(), nbk * 8, hipMemcpyHostToDevice, c->stream));  // cursors
                 {
                     Prof p(c, SAGE_K_COUNT);
-                    k_key_partition<1><<<cgrid, 256, 0, c->stream>>>(c->desc.as<uint4>(), A.tok_w0, n_tok, S,
+                    k_key_partition<1><<<cgrid, 256, 0, c->stream>>>(c->desc.as<uint4>(), c->pool.as<uint32_t>(),
+                                                                     c->occ_tok.as<uint32_t>(), A.tok_w0, n_occ, S,
                                                                      c->hist1.as<unsigned long long>(),
                                                                      c->rec_a.as<unsigned long long>());
-                    k_key_partition_over<1><<<64, 256, 0, c->stream>>>(A, n_tok, S, c->over_list.as<uint32_t>(),
-                                                                       c->over_count.as<uint32_t>(),
-                                                                       c->hist1.as<unsigned long long>(),
-                                                                       c->rec_a.as<unsigned long long>());
                     const uint32_t dgrid = (uint32_t)std::min<size_t>(nbk, 256u * 4u);
                     k_key_dedupe<<<dgrid, 256, 0, c->stream>>>(c->bucket_off.as<unsigned long long>(), (uint32_t)nbk,
                                                                c->rec_a.as<unsigned long long>(),
@@ -355,44 +383,40 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
                                                                c->stats.as<unsigned long long>(), c->flags.as<uint32_t>());
                 }
             } else {
-            // ---- v1: one distinct-key set per segment in HBM, sized from the exact pair count: load factor <= 0.5
-            std::vector<uint64_t> sbase(nsb), smask(nsb), spairs(nsb);
-            HIP_TRY(c, hipMemcpyAsync(spairs.data(), c->seg_pairs.p, (size_t)nsb * 8, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(c, hipMemcpyAsync(&n_over, c->over_count.p, 4, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            uint64_t slots = 0;
-            for (uint32_t s = 0; s < nsb; ++s) {
-                const uint64_t cap = pow2ceil(std::max<uint64_t>(64, spairs[s] * 2));
-                sbase[s] = slots; smask[s] = cap - 1; slots += cap;
+                // ---- v1: one distinct-key set per segment in HBM, sized from the exact pair count: load <= 0.5 ----
+                std::vector<uint64_t> sbase(nsb), smask(nsb), spairs(nsb);
+                HIP_TRY(c, hipMemcpyAsync(spairs.data(), c->seg_pairs.p, (size_t)nsb * 8, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipMemcpyAsync(&n_dots, c->grand_total.as<uint64_t>() + 1, 8, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                uint64_t slots = 0;
+                for (uint32_t s = 0; s < nsb; ++s) {
+                    const uint64_t cap = pow2ceil(std::max<uint64_t>(64, spairs[s] * 2));
+                    sbase[s] = slots; smask[s] = cap - 1; slots += cap;
+                }
+                if ((rc = ensure(c, c->set, slots * 8))) return rc;
+                HIP_TRY(c, hipMemcpyAsync(c->set_base.p, sbase.data(), (size_t)nsb * 8, hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(c, hipMemcpyAsync(c->set_mask.p, smask.data(), (size_t)nsb * 8, hipMemcpyHostToDevice, c->stream));
+                {
+                    Prof p(c, SAGE_K_MISC);
+                    HIP_TRY(c, hipMemsetAsync(c->set.p, 0xFF, slots * 8, c->stream));
+                }
+                {
+                    Prof p(c, SAGE_K_COUNT);
+                    k_count_sets<<<cgrid, 256, 0, c->stream>>>(c->desc.as<uint4>(), c->pool.as<uint32_t>(),
+                                                               c->occ_tok.as<uint32_t>(), A.tok_w0, n_occ, S,
+                                                               c->set.as<unsigned long long>(),
+                                                               c->stats.as<unsigned long long>(), c->flags.as<uint32_t>());
+                }
             }
-            if ((rc = ensure(c, c->set, slots * 8))) return rc;
-            HIP_TRY(c, hipMemcpyAsync(c->set_base.p, sbase.data(), (size_t)nsb * 8, hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(c, hipMemcpyAsync(c->set_mask.p, smask.data(), (size_t)nsb * 8, hipMemcpyHostToDevice, c->stream));
-            {
-                Prof p(c, SAGE_K_MISC);
-                HIP_TRY(c, hipMemsetAsync(c->set.p, 0xFF, slots * 8, c->stream));
-            }
-            {
-                Prof p(c, SAGE_K_COUNT);
-                k_count_desc<<<cgrid, 256, 0, c->stream>>>(c->desc.as<uint4>(), A.tok_w0, n_tok, S,
-                                                           c->set.as<unsigned long long>(),
-                                                           c->stats.as<unsigned long long>(), c->flags.as<uint32_t>());
-                if (n_over)
-                    k_ablate_count<true><<<64, 256, 0, c->stream>>>(
-                        A, n_tok, S, c->set.as<unsigned long long>(), nullptr, nullptr, nullptr, (uint32_t)hist_len,
-                        c->stats.as<unsigned long long>(), c->flags.as<uint32_t>(), c->over_list.as<uint32_t>(),
-                        c->over_count.as<uint32_t>());
-            }
-            }
-            {
-                const int dp = c->dp;
-                const bool ov = n_over > 0;
-                if (dp <= 32) launch_score<8, 4>(c, A, n_tok, ov);
-                else if (dp <= 64) launch_score<8, 8>(c, A, n_tok, ov);
-                else if (dp <= 128) launch_score<32, 4>(c, A, n_tok, ov);
-                else if (dp <= 256) launch_score<64, 4>(c, A, n_tok, ov);
-                else if (dp <= 384) launch_score<64, 6>(c, A, n_tok, ov);
-                else launch_score<64, 8>(c, A, n_tok, ov);
+            if (n_dots >= 0xFFFFFF00ull) return fail(c, SAGE_E_LIMIT, "a batch must stay under 2^32 ablated-window pairs");
+            if ((rc = ensure(c, c->dots, std::max<uint64_t>(n_dots, 1) * 8))) return rc;
+            switch (c->dp) {
+            case 32: launch_score<8, 4>(c, A.tok_w0, n_tok, n_occ); break;
+            case 64: launch_score<8, 8>(c, A.tok_w0, n_tok, n_occ); break;
+            case 128: launch_score<16, 8>(c, A.tok_w0, n_tok, n_occ); break;
+            case 256: launch_score<32, 8>(c, A.tok_w0, n_tok, n_occ); break;
+            case 384: launch_score<64, 6>(c, A.tok_w0, n_tok, n_occ); break;
+            default: launch_score<64, 8>(c, A.tok_w0, n_tok, n_occ); break;
             }
             HIP_TRY(c, hipGetLastError());
             sa = sb;
@@ -405,8 +429,13 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
         collect_events(c);
         if (flags[FLAG_EMPTY_LINE])
             return fail(c, SAGE_E_EMPTY_LINE, "not enough values to unpack (expected 3, got 0)");
+        if (flags[FLAG_POOL_FULL]) {
+            if (attempt >= 6) return fail(c, SAGE_E_LIMIT, "window-id pool overflowed");
+            c->pool_factor *= 4;   // long ablation chains: redo the step with a larger id pool
+            continue;
+        }
         if (flags[FLAG_SET_OVERFLOW]) {
-            if (attempt >= 1 || c->count_mode == 1) return fail(c, SAGE_E_LIMIT, "distinct-key set overflowed");
+            if (c->count_mode == 1) return fail(c, SAGE_E_LIMIT, "distinct-key set overflowed");
             c->count_mode = 1;   // exactness first: an LDS set overflowed (adversarial hash skew) -> redo with HBM sets
             continue;
         }
@@ -416,7 +445,7 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
         totals[1] = (int64_t)stats[STAT_DISTINCT];
         c->step_stats[0] = (int64_t)total_tokens;
         c->step_stats[1] = (int64_t)total_bytes;
-        c->step_stats[2] = (int64_t)stats[STAT_OCC];
+        c->step_stats[2] = (int64_t)total_occ;
         c->step_stats[3] = (int64_t)stats[STAT_ROWS];
         c->step_stats[4] = (int64_t)stats[STAT_PAIRS] * 2;   // signed (t,c) records: both orders
         c->step_stats[5] = (int64_t)stats[STAT_PAIRS];
@@ -458,7 +487,8 @@ void sage_destroy(sage_ctx* c) {
     for (auto e : c->ev_free) (void)hipEventDestroy(e);
     DevBuf* all[] = {&c->buckets, &c->keys, &c->byte_id, &c->bloom, &c->corpus, &c->rem, &c->line_off, &c->emb, &c->M, &c->ntok,
                      &c->tokoff, &c->tile_sums, &c->grand_total, &c->tok_w0, &c->tok_pos, &c->set, &c->seg_line_rel,
-                     &c->seg_tok_off, &c->set_base, &c->set_mask, &c->seg_pairs, &c->desc, &c->gcache, &c->over_list, &c->over_count, &c->hist1, &c->bucket_off, &c->rec_a, &c->rec_b, &c->ex_ids, &c->ex_starts, &c->ex_widths, &c->loss,
+                     &c->seg_tok_off, &c->set_base, &c->set_mask, &c->seg_pairs, &c->desc, &c->gcache, &c->hist1, &c->bucket_off, &c->rec_a, &c->rec_b, &c->nocc, &c->occoff, &c->occ_tok,
+                     &c->np_ab, &c->dot_off, &c->dots, &c->pool, &c->pool_cursor, &c->ex_ids, &c->ex_starts, &c->ex_widths, &c->loss,
                      &c->occ, &c->hist, &c->stats, &c->flags};
     for (DevBuf* b : all) release(*b);
     (void)hipStreamDestroy(c->stream);
@@ -567,7 +597,7 @@ int sage_set_embeddings(sage_ctx* c, const double* emb, int64_t rows, int32_t di
     if (!c || !emb || rows <= 0 || dim <= 0) return fail(c, SAGE_E_ARG, "bad argument");
     if (dim > 512) return fail(c, SAGE_E_LIMIT, "embedding dimension above 512 is not supported");
     HIP_TRY(c, hipSetDevice(c->device));
-    const int dp = dim <= 32 ? (dim + 7) / 8 * 8 : (dim + 15) / 16 * 16;  // whole 128-B lines per lane group
+    const int dp = padded_dim(dim);  // whole 128-byte lines per lane group
     int rc;
     if ((rc = ensure(c, c->emb, (size_t)rows * dp * 8))) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -612,7 +642,8 @@ int sage_tokenize(sage_ctx* c, int64_t line_begin, int64_t line_end, int32_t* ou
                 Prof p(c, SAGE_K_WALK);
                 k_walk_write<true><<<cdiv(nl, 256), 256, 0, c->stream>>>(
                     c->line_off.as<int64_t>(), l0, nl, c->h_line_off[l0], c->M.as<uint2>(), c->tokoff.as<uint32_t>(),
-                    nullptr, nullptr, c->ex_ids.as<int32_t>(), c->ex_starts.as<int32_t>(), c->ex_widths.as<int32_t>());
+                    nullptr, nullptr, nullptr, nullptr, c->ex_ids.as<int32_t>(), c->ex_starts.as<int32_t>(),
+                    c->ex_widths.as<int32_t>());
             }
             HIP_TRY(c, hipGetLastError());
             HIP_TRY(c, hipMemcpyAsync(out_ids + total, c->ex_ids.p, ntok * 4, hipMemcpyDeviceToHost, c->stream));

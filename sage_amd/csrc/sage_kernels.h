@@ -313,21 +313,28 @@ __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ 
 // ----------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_walk_count(const int64_t* __restrict__ line_off, int64_t line0,
                                                     uint32_t n_lines, int64_t pos0, const uint2* __restrict__ M,
-                                                    uint32_t* __restrict__ ntok, uint32_t* __restrict__ flags) {
+                                                    uint32_t* __restrict__ ntok, uint32_t* __restrict__ nocc,
+                                                    uint32_t* __restrict__ flags) {
     uint32_t l = blockIdx.x * 256u + threadIdx.x;
     if (l >= n_lines) return;
     uint32_t p = (uint32_t)(line_off[line0 + l] - pos0), e = (uint32_t)(line_off[line0 + l + 1] - pos0);
     if (p == e) flags[FLAG_EMPTY_LINE] = 1;
-    uint32_t c = 0;
-    while (p < e) { p += SAGE_M_LEN(M[p].x); ++c; }
+    uint32_t c = 0, mb = 0;
+    while (p < e) {
+        const uint32_t len = SAGE_M_LEN(M[p].x);
+        p += len; ++c; mb += len > 1u;
+    }
     ntok[l] = c;
+    nocc[l] = mb;   // tokens wider than one byte = ablated occurrences (model.py:170)
 }
 
 template <bool EXPORT>
 __global__ __launch_bounds__(256) void k_walk_write(const int64_t* __restrict__ line_off, int64_t line0,
                                                     uint32_t n_lines, int64_t pos0, const uint2* __restrict__ M,
                                                     const uint32_t* __restrict__ tok_off,
+                                                    const uint32_t* __restrict__ occ_off,
                                                     uint32_t* __restrict__ tok_w0, uint32_t* __restrict__ tok_pos,
+                                                    uint32_t* __restrict__ occ_tok,
                                                     int32_t* __restrict__ ex_ids, int32_t* __restrict__ ex_starts,
                                                     int32_t* __restrict__ ex_widths) {
     uint32_t l = blockIdx.x * 256u + threadIdx.x;
@@ -336,6 +343,7 @@ __global__ __launch_bounds__(256) void k_walk_write(const int64_t* __restrict__ 
     uint32_t p = p_begin, e = (uint32_t)(line_off[line0 + l + 1] - pos0);
     uint32_t t = tok_off[l], c = 0;
     const uint32_t nt = tok_off[l + 1] - t;
+    uint32_t o = EXPORT ? 0u : occ_off[l];
     while (p < e) {
         const uint32_t m = M[p].x;
         if (EXPORT) {
@@ -346,6 +354,7 @@ __global__ __launch_bounds__(256) void k_walk_write(const int64_t* __restrict__ 
             const uint32_t after = nt - 1u - c;
             tok_w0[t] = SAGE_M_ID(m) | ((c < 3u ? c : 3u) << 20) | ((after < 3u ? after : 3u) << 22);
             tok_pos[t] = p;
+            if (SAGE_M_LEN(m) > 1u) occ_tok[o++] = t;   // compact list of the tokens that get ablated
         }
         p += SAGE_M_LEN(m);
         ++t; ++c;
@@ -567,186 +576,11 @@ __device__ __forceinline__ uint32_t set_insert(unsigned long long* __restrict__ 
     return 0;
 }
 
-// Pass 0 (INSERT=false): histogram, occurrences and the number of position pairs of every segment (which sizes
-// that segment's set at load <= 0.5, so pass 1 can neither overflow nor degrade).  Pass 1 (INSERT=true): the
-// same walk inserting the keys.
-template <bool INSERT>
-__global__ __launch_bounds__(256) void k_ablate_count(WalkArrays A, uint32_t n_tok, SegPlan S,
-                                                      unsigned long long* __restrict__ set,
-                                                      unsigned long long* __restrict__ seg_pairs,
-                                                      unsigned long long* __restrict__ occ,
-                                                      unsigned long long* __restrict__ hist, uint32_t hist_len,
-                                                      unsigned long long* __restrict__ stats,
-                                                      uint32_t* __restrict__ flags,
-                                                      const uint32_t* __restrict__ list = nullptr,
-                                                      const uint32_t* __restrict__ n_list = nullptr) {
-    __shared__ unsigned int lhist[32];
-    const uint32_t n_items = list ? *n_list : n_tok;   // optional indirection: only the listed tokens
-    if (!INSERT) {
-        if (threadIdx.x < 32) lhist[threadIdx.x] = 0;
-        __syncthreads();
-    }
-    unsigned long long n_occ = 0, n_rows = 0, n_pairs = 0, n_distinct = 0;
-    const uint32_t n_round = (n_items + 63u) & ~63u;  // whole waves stay in the loop (wave-level reductions inside)
-    for (uint32_t it = blockIdx.x * 256u + threadIdx.x; it < n_round; it += gridDim.x * 256u) {
-        const uint32_t t = it < n_items ? (list ? list[it] : it) : 0xFFFFFFFFu;
-        Walker w;
-        const bool live = t < n_tok && w.init(A, t);
-        const uint32_t seg = t < n_tok ? find_segment(S, t) : 0xFFFFFFFFu;
-        unsigned long long my_pairs = 0;
-        if (live) {
-            const uint64_t base = INSERT ? S.set_base[seg] : 0, mask = INSERT ? S.set_mask[seg] : 0;
-            const uint64_t akey = (uint64_t)w.a << 40;
-            uint32_t id, p1 = 0, p2 = 0;
-            bool c, c1 = false, c2 = false, base_window = false;
-            int have = 0, fresh;
-            while (w.next(A, id, c, fresh)) {
-                if (fresh) { have = 0; base_window = fresh < 0; }
-                if (!base_window || c) ++n_rows;  // rows touched: pads + ablated + base span (SURVEY.md 8d r-bar)
-                if (have >= 1 && (c || c1)) {
-                    if (INSERT) {
-                        const uint32_t lo = min(id, p1), hi = max(id, p1);
-                        const uint32_t nw = set_insert(set, base, mask, akey | ((uint64_t)lo << 20) | hi, flags);
-                        n_distinct += nw ? (lo == hi ? 1u : 2u) : 0u;
-                    }
-                    ++my_pairs;
-                }
-                if (have >= 2 && (c || c2)) {
-                    if (INSERT) {
-                        const uint32_t lo = min(id, p2), hi = max(id, p2);
-                        const uint32_t nw = set_insert(set, base, mask, akey | ((uint64_t)lo << 20) | hi, flags);
-                        n_distinct += nw ? (lo == hi ? 1u : 2u) : 0u;
-                    }
-                    ++my_pairs;
-                }
-                p2 = p1; c2 = c1; p1 = id; c1 = c; ++have;
-            }
-            if (!INSERT) {
-                ++n_occ;
-                atomicAdd(&occ[w.a], 1ull);
-                const uint32_t kk = w.k < hist_len ? w.k : hist_len - 1u;
-                if (kk < 32u) atomicAdd(&lhist[kk], 1u); else atomicAdd(&hist[kk], 1ull);
-            }
-        }
-        n_pairs += my_pairs;
-        if (!INSERT) {
-            // pairs per segment: one atomic per wave when the wave sits inside one segment (the usual case)
-            const uint32_t seg0 = __shfl(seg, 0, 64);
-            if (__all(seg == seg0 || seg == 0xFFFFFFFFu) && seg0 != 0xFFFFFFFFu) {
-                unsigned long long v = my_pairs;
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
-                if ((threadIdx.x & 63u) == 0 && v) atomicAdd(&seg_pairs[seg0], v);
-            } else if (my_pairs) {
-                atomicAdd(&seg_pairs[seg], my_pairs);
-            }
-        }
-    }
-    if (!INSERT) {
-        __syncthreads();
-        if (threadIdx.x < 32 && threadIdx.x < hist_len && lhist[threadIdx.x])
-            atomicAdd(&hist[threadIdx.x], (unsigned long long)lhist[threadIdx.x]);
-    }
-    // wave-level reduction of the statistics, one atomic per wave
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        n_occ += __shfl_down(n_occ, d, 64);
-        n_rows += __shfl_down(n_rows, d, 64);
-        n_pairs += __shfl_down(n_pairs, d, 64);
-        n_distinct += __shfl_down(n_distinct, d, 64);
-    }
-    if ((threadIdx.x & 63u) == 0) {
-        if (!INSERT) {
-            if (n_occ) atomicAdd(&stats[STAT_OCC], n_occ);
-            if (n_rows) atomicAdd(&stats[STAT_ROWS], n_rows);
-            if (n_pairs) atomicAdd(&stats[STAT_PAIRS], n_pairs);
-        } else if (n_distinct) {
-            atomicAdd(&stats[STAT_DISTINCT], n_distinct);
-        }
-    }
-}
-
 // ----------------------------------------------------------------------------------------------------------
-// K3  score: loss[a] -= sign * count * log(sigmoid(E[t].E[c]))  (utils.py:125-138,255) evaluated directly per
-// occurrence in float64.  G lanes own one occurrence; a lane holds EPL elements of each of the last three
-// window rows, so every embedding row is fetched once per window as one coalesced segment.  The dot of a pair is
-// reduced across the G lanes; the G lanes then each take ONE of the pending dots through log-sigmoid, so the
-// transcendental work is not replicated.  Each position pair stands for both (t,c) orders: weight 2.
+// log(sigmoid(x)) in float64 (utils.py:136)
 // ----------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double log_sigmoid(double x) {
     // log(expit(x)) of utils.py:136 in its overflow-free form; equal to 1 ulp for |x| < 700
     return fmin(x, 0.0) - log1p(exp(-fabs(x)));
 }
 
-template <int G, int EPL>
-__global__ __launch_bounds__(256) void k_score(WalkArrays A, uint32_t n_tok, const double* __restrict__ emb,
-                                               uint32_t emb_rows, uint32_t dp, double* __restrict__ loss,
-                                               uint32_t* __restrict__ flags,
-                                               const uint32_t* __restrict__ list = nullptr,
-                                               const uint32_t* __restrict__ n_list = nullptr) {
-    const uint32_t n_items = list ? *n_list : n_tok;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t gl = lane % G;                       // lane inside the group
-    const uint32_t groups_per_block = 256 / G;
-    const uint32_t group0 = blockIdx.x * groups_per_block + threadIdx.x / G;
-    const uint32_t group_stride = gridDim.x * groups_per_block;
-
-    for (uint32_t t0 = blockIdx.x * groups_per_block; t0 < n_items; t0 += group_stride) {
-        const uint32_t it = t0 + threadIdx.x / G;
-        const uint32_t t = it < n_items ? (list ? list[it] : it) : 0xFFFFFFFFu;
-        (void)group0; (void)lane;
-        Walker w;
-        bool active = t < n_tok && w.init(A, t);
-        double r0[EPL], r1[EPL], r2[EPL];
-        bool c1 = false, c2 = false;
-        int have = 0;
-        double sign = 1.0, acc = 0.0, pend_val = 0.0, pend_sgn = 0.0;
-        int pend = 0;
-        while (__any(active)) {
-            if (active) {
-                uint32_t id; bool c; int fresh;
-                if (w.next(A, id, c, fresh)) {
-                    if (fresh) { have = 0; sign = fresh > 0 ? 1.0 : -1.0; }
-                    if (id >= emb_rows) { flags[FLAG_ROW_OOB] = 1; id = 0; }
-                    const double* row = emb + (size_t)id * dp;
-#pragma unroll
-                    for (int e = 0; e < EPL; ++e) {
-                        const uint32_t idx = gl + (uint32_t)G * e;
-                        r0[e] = idx < dp ? row[idx] : 0.0;
-                    }
-                    if (have >= 1 && (c || c1)) {
-                        double d = 0.0;
-#pragma unroll
-                        for (int e = 0; e < EPL; ++e) d = fma(r0[e], r1[e], d);
-#pragma unroll
-                        for (int m = G / 2; m >= 1; m >>= 1) d += __shfl_xor(d, m, G);
-                        if ((int)gl == pend) { pend_val = d; pend_sgn = sign; }
-                        ++pend;
-                    }
-                    if (have >= 2 && (c || c2)) {
-                        double d = 0.0;
-#pragma unroll
-                        for (int e = 0; e < EPL; ++e) d = fma(r0[e], r2[e], d);
-#pragma unroll
-                        for (int m = G / 2; m >= 1; m >>= 1) d += __shfl_xor(d, m, G);
-                        if ((int)gl == pend) { pend_val = d; pend_sgn = sign; }
-                        ++pend;
-                    }
-#pragma unroll
-                    for (int e = 0; e < EPL; ++e) { r2[e] = r1[e]; r1[e] = r0[e]; }
-                    c2 = c1; c1 = c; ++have;
-                } else {
-                    active = false;
-                }
-            }
-            // wave-synchronous flush: one log-sigmoid per lane covers G pending pairs of its group
-            if (__any(pend > G - 2) || !__any(active)) {
-                if ((int)gl < pend) acc += pend_sgn * log_sigmoid(pend_val);
-                pend = 0;
-            }
-        }
-#pragma unroll
-        for (int m = G / 2; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, G);
-        if (gl == 0 && t < n_tok && w.k > 0) unsafeAtomicAdd(&loss[w.a], -2.0 * acc);
-    }
-}

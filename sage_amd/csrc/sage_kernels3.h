@@ -17,22 +17,34 @@
 #define NB2_MAX 256
 
 // Calls f(lo, hi) for every position pair of the occurrence's two windows (model.py:115-136 via descriptors).
+// d = the 16 descriptor words in registers; long windows stream their ids from the pool.
 template <class F>
-__device__ __forceinline__ void keys_from_desc(const uint32_t (&d)[16], const uint32_t* __restrict__ tok_w0, uint32_t t,
-                                               F&& f) {
-    const uint32_t hdr = d[0];
-    const uint32_t k = SAGE_DH_K(hdr), m = SAGE_DH_M(hdr), pl = SAGE_DH_PL(hdr), pr = SAGE_DH_PR(hdr);
-    const uint32_t L = pl + k + pr;
+__device__ __forceinline__ void keys_from_desc(const uint32_t (&d)[16], const uint32_t* __restrict__ pool,
+                                               const uint32_t* __restrict__ tok_w0, uint32_t t, F&& f) {
+    const Win w = win_decode(d[0], d[2], d[3]);
+    const uint32_t pl = w.pl, k = w.k, m = w.m, pr = w.pr, L = w.L;
+    if (!w.pooled) {
 #pragma unroll
-    for (int j = 1; j < SAGE_DESC_MAXWIN; ++j) {
-        if ((uint32_t)j < L) {
-            const bool c = (uint32_t)j >= pl && (uint32_t)j < pl + k;
-            const bool c1 = (uint32_t)(j - 1) >= pl && (uint32_t)(j - 1) < pl + k;
-            if (c || c1) f(min(d[1 + j], d[j]), max(d[1 + j], d[j]));
-            if (j >= 2) {
-                const bool c2 = (uint32_t)(j - 2) >= pl && (uint32_t)(j - 2) < pl + k;
-                if (c || c2) f(min(d[1 + j], d[j - 1]), max(d[1 + j], d[j - 1]));
+        for (int j = 1; j < SAGE_DESC_MAXWIN; ++j) {
+            if ((uint32_t)j < L) {
+                const bool c = (uint32_t)j >= pl && (uint32_t)j < pl + k;
+                const bool c1 = (uint32_t)(j - 1) >= pl && (uint32_t)(j - 1) < pl + k;
+                if (c || c1) f(min(d[1 + j], d[j]), max(d[1 + j], d[j]));
+                if (j >= 2) {
+                    const bool c2 = (uint32_t)(j - 2) >= pl && (uint32_t)(j - 2) < pl + k;
+                    if (c || c2) f(min(d[1 + j], d[j - 1]), max(d[1 + j], d[j - 1]));
+                }
             }
+        }
+    } else {
+        const uint32_t* ids = pool + d[1];
+        uint32_t p1 = 0, p2 = 0;
+        for (uint32_t j = 0; j < L; ++j) {
+            const uint32_t id = ids[j];
+            const bool c = j >= pl && j < pl + k;
+            if (j >= 1) { const bool c1 = (j - 1) >= pl && (j - 1) < pl + k; if (c || c1) f(min(id, p1), max(id, p1)); }
+            if (j >= 2) { const bool c2 = (j - 2) >= pl && (j - 2) < pl + k; if (c || c2) f(min(id, p2), max(id, p2)); }
+            p2 = p1; p1 = id;
         }
     }
     const uint32_t w0 = t - pl, w1 = t + m + pr;  // base window tokens [w0, w1), centre [t, t+m)
@@ -46,22 +58,8 @@ __device__ __forceinline__ void keys_from_desc(const uint32_t (&d)[16], const ui
     }
 }
 
-// Same pairs for a window too long for a descriptor: stream the walker.
-template <class F>
-__device__ __forceinline__ void keys_from_walk(const WalkArrays& A, Walker& w, F&& f) {
-    uint32_t id, p1 = 0, p2 = 0;
-    bool c, c1 = false, c2 = false;
-    int have = 0, fresh;
-    while (w.next(A, id, c, fresh)) {
-        if (fresh) have = 0;
-        if (have >= 1 && (c || c1)) f(min(id, p1), max(id, p1));
-        if (have >= 2 && (c || c2)) f(min(id, p2), max(id, p2));
-        p2 = p1; c2 = c1; p1 = id; c1 = c; ++have;
-    }
-}
-
-__device__ __forceinline__ void load_desc(const uint4* __restrict__ desc, uint32_t t, uint32_t (&d)[16]) {
-    const uint4 a = desc[(size_t)t * 4], b = desc[(size_t)t * 4 + 1], c = desc[(size_t)t * 4 + 2], e = desc[(size_t)t * 4 + 3];
+__device__ __forceinline__ void load_desc(const uint4* __restrict__ desc, uint32_t o, uint32_t (&d)[16]) {
+    const uint4 a = desc[(size_t)o * 4], b = desc[(size_t)o * 4 + 1], c = desc[(size_t)o * 4 + 2], e = desc[(size_t)o * 4 + 3];
     d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
     d[8] = c.x; d[9] = c.y; d[10] = c.z; d[11] = c.w; d[12] = e.x; d[13] = e.y; d[14] = e.z; d[15] = e.w;
 }
@@ -70,33 +68,60 @@ __device__ __forceinline__ uint64_t make_key(uint32_t a, uint32_t lo, uint32_t h
     return ((uint64_t)a << 40) | ((uint64_t)lo << 20) | hi;
 }
 
-// ---- pass 1: counts per (segment, coarse bucket) ------------------------------------------------------------
-// MODE 0: count into hist1.  MODE 1: scatter into rec using cursor (which starts at each bucket's base offset).
-// A tile of 256 consecutive tokens touches at most two segments in practice; those go through LDS counters and
-// one global atomic per (tile, bucket); anything else takes one global atomic per key.
+// ---- v1 back end (count mode 1): per-segment u64 open-addressed sets in HBM, one CAS per key ---------------
+__global__ __launch_bounds__(256) void k_count_sets(const uint4* __restrict__ desc, const uint32_t* __restrict__ pool,
+                                                    const uint32_t* __restrict__ occ_tok,
+                                                    const uint32_t* __restrict__ tok_w0, uint32_t n_occ, SegPlan S,
+                                                    unsigned long long* __restrict__ set,
+                                                    unsigned long long* __restrict__ stats, uint32_t* __restrict__ flags) {
+    unsigned long long n_distinct = 0;
+    for (uint32_t o = blockIdx.x * 256u + threadIdx.x; o < n_occ; o += gridDim.x * 256u) {
+        uint32_t d[16];
+        load_desc(desc, o, d);
+        const uint32_t t = occ_tok[o];
+        const uint32_t seg = find_segment(S, t);
+        const uint64_t base = S.set_base[seg], mask = S.set_mask[seg];
+        const uint32_t a = SAGE_T_ID(tok_w0[t]);
+        keys_from_desc(d, pool, tok_w0, t, [&](uint32_t lo, uint32_t hi) {
+            const uint32_t nw = set_insert(set, base, mask, make_key(a, lo, hi), flags);
+            n_distinct += nw ? (lo == hi ? 1u : 2u) : 0u;
+        });
+    }
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) n_distinct += __shfl_down(n_distinct, dd, 64);
+    if ((threadIdx.x & 63u) == 0 && n_distinct) atomicAdd(&stats[STAT_DISTINCT], n_distinct);
+}
+
+// ---- passes 1 and 2: counts per (segment, coarse bucket), then the scatter ---------------------------------------
+// MODE 0: count into `counters`.  MODE 1: scatter into rec using `counters` as cursors (they start at each bucket's
+// base offset).  A tile of 256 consecutive occurrences touches at most two segments in practice; those go through
+// LDS counters and one global atomic per (tile, bucket); anything else takes one global atomic per key.
 template <int MODE>
-__global__ __launch_bounds__(256) void k_key_partition(const uint4* __restrict__ desc, const uint32_t* __restrict__ tok_w0,
-                                                       uint32_t n_tok, SegPlan S, unsigned long long* __restrict__ counters,
+__global__ __launch_bounds__(256) void k_key_partition(const uint4* __restrict__ desc, const uint32_t* __restrict__ pool,
+                                                       const uint32_t* __restrict__ occ_tok,
+                                                       const uint32_t* __restrict__ tok_w0, uint32_t n_occ, SegPlan S,
+                                                       unsigned long long* __restrict__ counters,
                                                        unsigned long long* __restrict__ rec) {
     __shared__ unsigned int cnt[2][NB1];
     __shared__ unsigned long long gbase[2][NB1];
-    const uint32_t n_round = (n_tok + 255u) & ~255u;
+    const uint32_t n_round = (n_occ + 255u) & ~255u;
     for (uint32_t base = blockIdx.x * 256u; base < n_round; base += gridDim.x * 256u) {
-        const uint32_t t = base + threadIdx.x;
+        const uint32_t o = base + threadIdx.x;
         if (threadIdx.x < 2 * NB1) cnt[threadIdx.x / NB1][threadIdx.x % NB1] = 0;
-        const uint32_t s0 = find_segment(S, base);
+        const uint32_t s0 = find_segment(S, occ_tok[base]);
         uint32_t d[16];
-        bool live = false;
-        uint32_t seg = 0, a = 0;
-        if (t < n_tok) {
-            load_desc(desc, t, d);
-            live = (d[0] & SAGE_DH_VALID) && !(d[0] & SAGE_DH_OVER);
-            if (live) { seg = find_segment(S, t); a = SAGE_T_ID(tok_w0[t]); }
+        const bool live = o < n_occ;
+        uint32_t seg = 0, a = 0, t = 0;
+        if (live) {
+            load_desc(desc, o, d);
+            t = occ_tok[o];
+            seg = find_segment(S, t);
+            a = SAGE_T_ID(tok_w0[t]);
         }
         const bool local = live && (seg - s0) < 2u;
         __syncthreads();
         if (live) {
-            keys_from_desc(d, tok_w0, t, [&](uint32_t lo, uint32_t hi) {
+            keys_from_desc(d, pool, tok_w0, t, [&](uint32_t lo, uint32_t hi) {
                 const uint64_t key = make_key(a, lo, hi);
                 const uint32_t b1 = (uint32_t)sage_mix64(key) & (NB1 - 1);
                 if (local) atomicAdd(&cnt[seg - s0][b1], 1u);
@@ -117,7 +142,7 @@ __global__ __launch_bounds__(256) void k_key_partition(const uint4* __restrict__
         if (MODE == 1) {
             __syncthreads();
             if (local) {
-                keys_from_desc(d, tok_w0, t, [&](uint32_t lo, uint32_t hi) {
+                keys_from_desc(d, pool, tok_w0, t, [&](uint32_t lo, uint32_t hi) {
                     const uint64_t key = make_key(a, lo, hi);
                     const uint32_t b1 = (uint32_t)sage_mix64(key) & (NB1 - 1);
                     const uint32_t r = atomicAdd(&cnt[seg - s0][b1], 1u);
@@ -126,29 +151,6 @@ __global__ __launch_bounds__(256) void k_key_partition(const uint4* __restrict__
             }
         }
         __syncthreads();
-    }
-}
-
-// Over-long windows (listed by k_describe): one global atomic per key, same two modes.
-template <int MODE>
-__global__ __launch_bounds__(256) void k_key_partition_over(WalkArrays A, uint32_t n_tok, SegPlan S,
-                                                            const uint32_t* __restrict__ list,
-                                                            const uint32_t* __restrict__ n_list,
-                                                            unsigned long long* __restrict__ counters,
-                                                            unsigned long long* __restrict__ rec) {
-    const uint32_t n = *n_list;
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        const uint32_t t = list[i];
-        Walker w;
-        if (t >= n_tok || !w.init(A, t)) continue;
-        const uint32_t seg = find_segment(S, t);
-        const uint32_t a = w.a;
-        keys_from_walk(A, w, [&](uint32_t lo, uint32_t hi) {
-            const uint64_t key = make_key(a, lo, hi);
-            const uint32_t b1 = (uint32_t)sage_mix64(key) & (NB1 - 1);
-            if (MODE == 0) atomicAdd(&counters[(size_t)seg * NB1 + b1], 1ull);
-            else rec[atomicAdd(&counters[(size_t)seg * NB1 + b1], 1ull)] = key;
-        });
     }
 }
 
