@@ -193,14 +193,35 @@ __device__ __forceinline__ void load_row_slice(const double* __restrict__ emb, u
         r[2 * i] = v.x; r[2 * i + 1] = v.y;
     }
 }
+// Sum over the G lanes of a group, result in every lane.  The first levels are DPP moves inside a 16-lane row
+// (quad_perm xor 1, xor 2, row_half_mirror, row_mirror): VALU only, no trip through the LDS crossbar.
+__device__ __forceinline__ double dpp_add(double v, const int ctrl_sel) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    int plo, phi;
+    switch (ctrl_sel) {
+    case 0: plo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, false); phi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, false); break;
+    case 1: plo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, false); phi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, false); break;
+    case 2: plo = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xF, 0xF, false); phi = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xF, 0xF, false); break;
+    default: plo = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xF, 0xF, false); phi = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xF, 0xF, false); break;
+    }
+    return v + __hiloint2double(phi, plo);
+}
+template <int G>
+__device__ __forceinline__ double group_sum(double d) {
+    d = dpp_add(d, 0);
+    d = dpp_add(d, 1);
+    d = dpp_add(d, 2);
+    if (G >= 16) d = dpp_add(d, 3);
+#pragma unroll
+    for (int m = 16; m < G; m <<= 1) d += __shfl_xor(d, m, G);
+    return d;
+}
 template <int G, int EPL>
 __device__ __forceinline__ double group_dot(const double (&a)[EPL], const double (&b)[EPL]) {
     double d = 0.0;
 #pragma unroll
     for (int e = 0; e < EPL; ++e) d = fma(a[e], b[e], d);
-#pragma unroll
-    for (int m = G / 2; m >= 1; m >>= 1) d += __shfl_xor(d, m, G);
-    return d;
+    return group_sum<G>(d);
 }
 
 // ----------------------------------------------------------------------------------------------------------
@@ -273,7 +294,7 @@ __global__ __launch_bounds__(256) void k_dots(const uint4* __restrict__ desc, co
     // Each element travelling through the pipeline carries: its row slice and a meta word
     //   bit0: dot with the previous element, bit1: dot with the one before, bit2: first element of an occurrence,
     //   bit3: element exists.  `out` is only read at a first element.
-    double r0[EPL], r1[EPL], r2[EPL], ra[EPL], rb[EPL];
+    double B0[EPL], B1[EPL], B2[EPL], B3[EPL], B4[EPL];   // ring of row slices; roles rotate, data never moves
     uint32_t m0 = 0, ma = 0, mb = 0, outa = 0, outb = 0, out0 = 0;
     // fetch side
     uint32_t fo = gid, fj = 0, fL = 0, fpl = 0, fk = 0;
@@ -304,29 +325,36 @@ __global__ __launch_bounds__(256) void k_dots(const uint4* __restrict__ desc, co
             if (fo >= n_occ) f_more = false;
         }
     };
-    fetch(ra, ma, outa);
-    fetch(rb, mb, outb);
     uint32_t wr = 0;   // write cursor into dots[]
-    while (__any(ma & 8u)) {
-        // rotate: the oldest in-flight row becomes current
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) { r2[e] = r1[e]; r1[e] = r0[e]; r0[e] = ra[e]; ra[e] = rb[e]; }
-        m0 = ma; out0 = outa; ma = mb; outa = outb;
-        fetch(rb, mb, outb);
-        if (m0 & 8u) {
-            if (m0 & 4u) wr = out0;
-            if (m0 & 1u) {
-                const double d = group_dot<G, EPL>(r0, r1);
-                if (gl == 0) dots[wr] = d;
-                ++wr;
-            }
-            if (m0 & 2u) {
-                const double d = group_dot<G, EPL>(r0, r2);
-                if (gl == 0) dots[wr] = d;
-                ++wr;
-            }
-        }
+    // one pipeline step: CUR becomes current (its load was issued two steps ago), NXT receives a new fetch
+#define SAGE_DOT_STEP(CUR, P1, P2, NXT)                                     \
+    {                                                                       \
+        m0 = ma; out0 = outa; ma = mb; outa = outb;                         \
+        fetch(NXT, mb, outb);                                               \
+        if (m0 & 8u) {                                                      \
+            if (m0 & 4u) wr = out0;                                         \
+            if (m0 & 1u) {                                                  \
+                const double d_ = group_dot<G, EPL>(CUR, P1);               \
+                if (gl == 0) dots[wr] = d_;                                 \
+                ++wr;                                                       \
+            }                                                               \
+            if (m0 & 2u) {                                                  \
+                const double d_ = group_dot<G, EPL>(CUR, P2);               \
+                if (gl == 0) dots[wr] = d_;                                 \
+                ++wr;                                                       \
+            }                                                               \
+        }                                                                   \
     }
+    fetch(B0, ma, outa);
+    fetch(B1, mb, outb);
+    while (__any(ma & 8u)) {
+        SAGE_DOT_STEP(B0, B4, B3, B2)
+        SAGE_DOT_STEP(B1, B0, B4, B3)
+        SAGE_DOT_STEP(B2, B1, B0, B4)
+        SAGE_DOT_STEP(B3, B2, B1, B0)
+        SAGE_DOT_STEP(B4, B3, B2, B1)
+    }
+#undef SAGE_DOT_STEP
 }
 
 // ----------------------------------------------------------------------------------------------------------

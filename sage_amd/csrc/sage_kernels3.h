@@ -15,6 +15,7 @@
 #define SET_SLOTS 4096   // LDS set capacity (u64 slots, 32 KiB)
 #define SET_FILL 2048    // at most this many records are offered to one set pass (load <= 0.5)
 #define NB2_MAX 256
+#define UNR 8          // keys a thread keeps in flight in the streaming loops of k_key_dedupe
 
 // Calls f(lo, hi) for every position pair of the occurrence's two windows (model.py:115-136 via descriptors).
 // d = the 16 descriptor words in registers; long windows stream their ids from the pool.
@@ -190,9 +191,13 @@ __global__ __launch_bounds__(256) void k_key_dedupe(const unsigned long long* __
             // fine partition inside the block: histogram, exclusive scan, scatter into tmp
             for (uint32_t i = threadIdx.x; i < nb2; i += 256) hist2[i] = 0;
             __syncthreads();
-            for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
-                const uint64_t h = sage_mix64(in[i]);
-                atomicAdd(&hist2[(uint32_t)(h >> 6) & (nb2 - 1)], 1u);
+            for (uint32_t i0 = threadIdx.x; i0 < cnt; i0 += 256 * UNR) {
+                uint64_t kk[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) kk[u] = (i0 + 256u * u) < cnt ? in[i0 + 256u * u] : 0ull;
+#pragma unroll
+                for (int u = 0; u < UNR; ++u)
+                    if ((i0 + 256u * u) < cnt) atomicAdd(&hist2[(uint32_t)(sage_mix64(kk[u]) >> 6) & (nb2 - 1)], 1u);
             }
             __syncthreads();
             {   // exclusive scan of up to 256 counters by the 256 threads
@@ -212,11 +217,16 @@ __global__ __launch_bounds__(256) void k_key_dedupe(const unsigned long long* __
                 if (threadIdx.x == 0) offs2[nb2] = cnt;
             }
             __syncthreads();
-            for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
-                const uint64_t key = in[i];
-                const uint64_t h = sage_mix64(key);
-                const uint32_t r = atomicAdd(&hist2[(uint32_t)(h >> 6) & (nb2 - 1)], 1u);
-                tmp[r] = key;
+            for (uint32_t i0 = threadIdx.x; i0 < cnt; i0 += 256 * UNR) {
+                uint64_t kk[UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) kk[u] = (i0 + 256u * u) < cnt ? in[i0 + 256u * u] : 0ull;
+#pragma unroll
+                for (int u = 0; u < UNR; ++u)
+                    if ((i0 + 256u * u) < cnt) {
+                        const uint32_t r = atomicAdd(&hist2[(uint32_t)(sage_mix64(kk[u]) >> 6) & (nb2 - 1)], 1u);
+                        tmp[r] = kk[u];
+                    }
             }
             __threadfence_block();
             __syncthreads();
@@ -232,11 +242,17 @@ __global__ __launch_bounds__(256) void k_key_dedupe(const unsigned long long* __
             for (uint32_t p = 0; p < passes; ++p) {
                 for (uint32_t i = threadIdx.x; i < SET_SLOTS; i += 256) set[i] = SAGE_SET_EMPTY;
                 __syncthreads();
-                for (uint32_t i = threadIdx.x; i < fn; i += 256) {
-                    const uint64_t key = src[f0 + i];
-                    const uint64_t h = sage_mix64(key);
-                    if (passes == 1 || ((uint32_t)(h >> 14) & 0x3FFFFu) % passes == p)
-                        n_distinct += lds_set_insert(set, key, h, flags);
+                for (uint32_t i0 = threadIdx.x; i0 < fn; i0 += 256 * UNR) {
+                    uint64_t kk[UNR];
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) kk[u] = (i0 + 256u * u) < fn ? src[f0 + i0 + 256u * u] : 0ull;
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u)
+                        if ((i0 + 256u * u) < fn) {
+                            const uint64_t h = sage_mix64(kk[u]);
+                            if (passes == 1 || ((uint32_t)(h >> 14) & 0x3FFFFu) % passes == p)
+                                n_distinct += lds_set_insert(set, kk[u], h, flags);
+                        }
                 }
                 __syncthreads();
             }
