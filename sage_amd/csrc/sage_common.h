@@ -25,15 +25,19 @@ SAGE_HD uint32_t sage_mix32(uint32_t x) {   // one multiply: v_mul_lo_u32 is qua
 }
 // A vocab-table slot: id[0:20) | (len-1)[20:25) | tag[25:32).  A bucket is 4 slots (one 16-byte load), filled in
 // order; a bucket whose last slot is empty terminates a probe sequence.
+// The 7-bit tag never takes the value 0x7F, so the top 12 bits of a live slot are never 0xFFF: an empty slot
+// (0xFFFFFFFF) cannot pass a tag+length comparison and needs no separate test in the matcher's inner loop.
+SAGE_HD uint32_t sage_slot_tag(uint32_t f) { const uint32_t t = f >> 25; return t < 0x7Eu ? t : 0x7Eu; }
 SAGE_HD uint32_t sage_slot_make(uint32_t id, uint32_t len, uint32_t f) {
-    return id | ((len - 1u) << 20) | ((f >> 25) << 25);
+    return id | ((len - 1u) << 20) | (sage_slot_tag(f) << 25);
 }
-SAGE_HD uint32_t sage_slot_want(uint32_t len, uint32_t f) { return ((f >> 25) << 5) | (len - 1u); }
+SAGE_HD uint32_t sage_slot_want(uint32_t len, uint32_t f) { return (sage_slot_tag(f) << 5) | (len - 1u); }
 
-// LDS presence filter of the matcher: 2^20 bits (128 KiB), two bit positions per key from its finalised hash.
+// LDS presence filter of the matcher: 2^20 bits (128 KiB) as 32,768 words; a key sets two bits inside ONE word
+// (blocked Bloom filter: a membership test is a single LDS read).
 #define SAGE_BLOOM_BITS (1u << 20)
-SAGE_HD uint32_t sage_bloom_bit1(uint32_t f) { return f >> 12; }
-SAGE_HD uint32_t sage_bloom_bit2(uint32_t f) { return (((f << 9) | (f >> 23)) ^ (f >> 5)) & (SAGE_BLOOM_BITS - 1u); }
+SAGE_HD uint32_t sage_bloom_word(uint32_t f) { return (f >> 7) & 0x7FFFu; }
+SAGE_HD uint32_t sage_bloom_mask(uint32_t f) { return (1u << (f & 31u)) | (1u << ((f >> 22) & 31u)); }
 
 SAGE_HD uint64_t sage_mix64(uint64_t k) {
     k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;

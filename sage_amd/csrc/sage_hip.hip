@@ -526,9 +526,7 @@ int sage_set_vocab(sage_ctx* c, const uint8_t* key_bytes, const int64_t* key_off
         for (uint32_t j = 0; j < len; ++j) h = sage_fnv_step(h, k[j]);
         const uint32_t f = sage_mix32(h);
         {
-            const uint32_t i1 = sage_bloom_bit1(f), i2 = sage_bloom_bit2(f);
-            bloom[i1 >> 5] |= 1u << (i1 & 31u);
-            bloom[i2 >> 5] |= 1u << (i2 & 31u);
+            bloom[sage_bloom_word(f)] |= sage_bloom_mask(f);
         }
         uint32_t b = f & bmask;
         for (;;) {

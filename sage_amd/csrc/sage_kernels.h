@@ -164,58 +164,73 @@ __device__ __forceinline__ bool probe_exact(const VocabDev& v, uint32_t b, uint3
     }
 }
 
+// The two longest matches found so far, longest first (hits = how many are filled in).
+struct Top2 {
+    uint32_t id1, len1, id2, len2, hits;
+};
+
 // Probes the candidate lengths JLO..JHI (at most 8) with all loads of a phase in flight together.  Branch-free:
 // a lane that has no candidate at a length loads bucket 0 / key 0 instead (one shared cache line), which costs
-// far less than the exec-mask bookkeeping of a divergent branch per length.
-// hitm gets bit (j-1) for every matching length, hid[j - JLO] its id.
+// far less than the exec-mask bookkeeping of a divergent branch per length.  Lengths are folded into `top`
+// from the longest down.  wantf[j] = (tag << 25) | ((j-1) << 20): a slot matches when slot ^ wantf < 2^20.
 template <int NW, int JLO, int JHI, int ML>
-__device__ __forceinline__ void probe_chunk(const VocabDev& v, uint32_t cand, const uint32_t (&want)[ML + 1],
-                                            const uint32_t (&bidx)[ML + 1], const uint64_t (&W)[NW], uint32_t& hitm,
-                                            uint32_t (&hid)[8]) {
+__device__ __forceinline__ void probe_chunk(const VocabDev& v, uint32_t cand, const uint32_t (&wantf)[ML + 1],
+                                            const uint32_t (&bidx)[ML + 1], const uint64_t (&W)[NW], Top2& top) {
     constexpr int N = JHI - JLO + 1;
     uint4 bk[N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) bk[i] = v.buckets[((cand >> (JLO + i - 1)) & 1u) ? bidx[JLO + i] : 0u];
+    for (int i = 0; i < N; ++i) {
+        // 0 or ~0 from the candidate bit without going through a condition register
+        const uint32_t onm = (uint32_t)(((int32_t)(cand << (32 - (JLO + i)))) >> 31);
+        bk[i] = v.buckets[bidx[JLO + i] & onm];
+    }
     uint32_t cid[N];
-    uint32_t have = 0, slow = 0;
+    bool have[N], full[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const uint32_t on = (cand >> (JLO + i - 1)) & 1u;
-        const uint32_t w = want[JLO + i];
-        const uint32_t m0 = (bk[i].x != SAGE_SLOT_EMPTY) & ((bk[i].x >> 20) == w);
-        const uint32_t m1 = (bk[i].y != SAGE_SLOT_EMPTY) & ((bk[i].y >> 20) == w);
-        const uint32_t m2 = (bk[i].z != SAGE_SLOT_EMPTY) & ((bk[i].z >> 20) == w);
-        const uint32_t m3 = (bk[i].w != SAGE_SLOT_EMPTY) & ((bk[i].w >> 20) == w);
-        const uint32_t nmatch = m0 + m1 + m2 + m3;
-        cid[i] = (m0 ? bk[i].x : (m1 ? bk[i].y : (m2 ? bk[i].z : bk[i].w))) & SAGE_ID_MASK;
-        const uint32_t full = bk[i].w != SAGE_SLOT_EMPTY;
-        have |= (on & (nmatch == 1u)) << i;
-        // two tag matches in one bucket, or a full bucket with no match: resolve exactly, one length at a time
-        slow |= (on & ((nmatch > 1u) | ((nmatch == 0u) & full))) << i;
+        const uint32_t w = wantf[JLO + i];
+        const bool m0 = (bk[i].x ^ w) < (1u << 20), m1 = (bk[i].y ^ w) < (1u << 20);
+        const bool m2 = (bk[i].z ^ w) < (1u << 20), m3 = (bk[i].w ^ w) < (1u << 20);
+        uint32_t c = bk[i].x;
+        c = m1 ? bk[i].y : c;
+        c = m2 ? bk[i].z : c;
+        c = m3 ? bk[i].w : c;
+        cid[i] = c & SAGE_ID_MASK;
+        have[i] = (m0 | m1 | m2 | m3) && ((cand >> (JLO + i - 1)) & 1u);
+        full[i] = bk[i].w != SAGE_SLOT_EMPTY;
     }
     uint64_t K[N][NW];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const uint64_t* key = v.keys + (size_t)(((have >> i) & 1u) ? cid[i] : 0u) * 4;
+        const uint64_t* key = v.keys + (size_t)(have[i] ? cid[i] : 0u) * 4;
 #pragma unroll
         for (int w = 0; w < NW; ++w)
             if (JLO + i - 8 * w > 0) K[i][w] = key[w];
     }
+    uint32_t hitm = 0, slow = 0;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const uint32_t hv = (have >> i) & 1u;
-        const uint32_t eq = key_equal<NW>(W, K[i], JLO + i) ? 1u : 0u;
-        hitm |= (hv & eq) << (JLO + i - 1);
-        hid[i] = cid[i];
-        slow |= (hv & (eq ^ 1u) & (uint32_t)(bk[i].w != SAGE_SLOT_EMPTY)) << i;  // tag false positive in a full bucket
+        const bool eq = key_equal<NW>(W, K[i], JLO + i);
+        const bool on = (cand >> (JLO + i - 1)) & 1u;
+        hitm |= (have[i] && eq) ? (1u << i) : 0u;
+        // rare: a tag match that fails the key compare, or a full bucket without a match -> exact serial probe
+        slow |= (on && !(have[i] && eq) && (have[i] || full[i])) ? (1u << i) : 0u;
     }
     if (slow) {
 #pragma unroll
         for (int i = 0; i < N; ++i)
             if ((slow >> i) & 1u) {
                 uint32_t id;
-                if (probe_exact<NW>(v, bidx[JLO + i], want[JLO + i], W, JLO + i, id)) { hitm |= 1u << (JLO + i - 1); hid[i] = id; }
+                if (probe_exact<NW>(v, bidx[JLO + i], wantf[JLO + i] >> 20, W, JLO + i, id)) { hitm |= 1u << i; cid[i] = id; }
             }
+    }
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) {
+        const bool take = ((hitm >> i) & 1u) && top.hits < 2u;
+        const bool first = take && top.hits == 0u, second = take && top.hits == 1u;
+        top.id1 = first ? cid[i] : top.id1;  top.len1 = first ? (uint32_t)(JLO + i) : top.len1;
+        top.id2 = second ? cid[i] : top.id2; top.len2 = second ? (uint32_t)(JLO + i) : top.len2;
+        top.hits += take ? 1u : 0u;
     }
 }
 
@@ -252,58 +267,50 @@ __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ 
 #pragma unroll
             for (int i = 0; i < 2 * NW; ++i) T[i] = __funnelshift_r(d[i], d[i + 1], sh);
         }
-        const int lim = min((int)rem[blk0 + tid], v.max_len);
-        uint32_t want[ML + 1];
+        const uint32_t lim = min((uint32_t)rem[blk0 + tid], (uint32_t)v.max_len);
+        uint32_t wantf[ML + 1];
         uint32_t bidx[ML + 1];
-        uint32_t cand = 0;
+        uint32_t miss = 0;   // bit (j-1) set when the filter rules length j out
         uint32_t h = sage_fnv_step(SAGE_FNV_OFFSET, T[0] & 0xFFu);
 #pragma unroll
         for (int j = 2; j <= ML; ++j) {
             const uint32_t b = (T[(j - 1) >> 2] >> (8 * ((j - 1) & 3))) & 0xFFu;
             h = sage_fnv_step(h, b);
             const uint32_t f = sage_mix32(h);
-            want[j] = sage_slot_want(j, f);
+            wantf[j] = (sage_slot_tag(f) << 25) | ((uint32_t)(j - 1) << 20);
             bidx[j] = f & v.bucket_mask;
-            const uint32_t i1 = sage_bloom_bit1(f), i2 = sage_bloom_bit2(f);
-            const bool maybe = j <= lim && ((bloom[i1 >> 5] >> (i1 & 31u)) & (bloom[i2 >> 5] >> (i2 & 31u)) & 1u);
-            if (maybe) cand |= 1u << (j - 1);
+            const uint32_t mk = sage_bloom_mask(f);
+            const uint32_t lack = (bloom[sage_bloom_word(f)] & mk) ^ mk;      // 0 when both bits are present
+            miss |= min(lack, 1u) << (j - 1);
         }
+        // candidate lengths: pass the filter, 2 <= j <= lim
+        const uint32_t cand = ~miss & ((lim >= 32u ? 0xFFFFFFFFu : ((1u << lim) - 1u)) & ~1u) & (ML >= 32 ? 0xFFFFFFFFu : ((1u << ML) - 1u));
         uint64_t W[NW];
 #pragma unroll
         for (int w = 0; w < NW; ++w) W[w] = (uint64_t)T[2 * w] | ((uint64_t)T[2 * w + 1] << 32);
-        uint32_t hitm = 0;
-        uint32_t hid[NW][8];
-        // chunks from the longest lengths down; a chunk is skipped when two matches are already known
-        // a chunk runs if ANY lane of the wave still needs it (wave-uniform branch); lanes that do not take part in it
-        // are masked through their candidate bits, not through EXEC
+        Top2 top{0, 0, 0, 0, 0};
+        // chunks from the longest lengths down.  A chunk runs if ANY lane of the wave still needs it (wave-uniform
+        // branch); lanes that do not take part are masked through their candidate bits, not through EXEC.
         if constexpr (NW >= 4) {
-            if (__any((cand >> 24) != 0u)) probe_chunk<NW, 25, 32, ML>(v, cand, want, bidx, W, hitm, hid[3]);
+            if (__any((cand >> 24) != 0u)) probe_chunk<NW, 25, 32, ML>(v, cand, wantf, bidx, W, top);
         }
         if constexpr (NW >= 3) {
-            const uint32_t c3 = __popc(hitm) < 2 ? cand : 0u;
-            if (__any(((c3 >> 16) & 0xFFu) != 0u)) probe_chunk<NW, 17, 24, ML>(v, c3, want, bidx, W, hitm, hid[2]);
+            const uint32_t c3 = top.hits < 2u ? cand : 0u;
+            if (__any(((c3 >> 16) & 0xFFu) != 0u)) probe_chunk<NW, 17, 24, ML>(v, c3, wantf, bidx, W, top);
         }
         if constexpr (NW >= 2) {
-            const uint32_t c2 = __popc(hitm) < 2 ? cand : 0u;
-            if (__any(((c2 >> 8) & 0xFFu) != 0u)) probe_chunk<NW, 9, 16, ML>(v, c2, want, bidx, W, hitm, hid[1]);
+            const uint32_t c2 = top.hits < 2u ? cand : 0u;
+            if (__any(((c2 >> 8) & 0xFFu) != 0u)) probe_chunk<NW, 9, 16, ML>(v, c2, wantf, bidx, W, top);
         }
         {
-            const uint32_t c1 = __popc(hitm) < 2 ? cand : 0u;
-            if (__any((c1 & 0xFFu) != 0u)) probe_chunk<NW, 2, 8, ML>(v, c1, want, bidx, W, hitm, hid[0]);
+            const uint32_t c1 = top.hits < 2u ? cand : 0u;
+            if (__any((c1 & 0xFFu) != 0u)) probe_chunk<NW, 2, 8, ML>(v, c1, wantf, bidx, W, top);
         }
-        // the two longest matches (the single byte always matches)
+        // the single byte always matches: it is the longest match when nothing else hit, the second when one did
         const uint32_t idb = v.byte_id[T[0] & 0xFFu];
-        uint32_t id1 = idb, len1 = 1, id2 = 0, len2 = 0, hits = 0;
-#pragma unroll
-        for (int j = ML; j >= 2; --j) {
-            if (hits < 2u && ((hitm >> (j - 1)) & 1u)) {
-                const uint32_t id = hid[(j - 1) / 8 >= NW ? NW - 1 : (j <= 8 ? 0 : (j - 1) / 8)][j <= 8 ? j - 2 : (j - 1) % 8];
-                if (hits == 0u) { id1 = id; len1 = (uint32_t)j; } else { id2 = id; len2 = (uint32_t)j; }
-                ++hits;
-            }
-        }
-        if (hits == 1u) { id2 = idb; len2 = 1; }
-        M[rel] = make_uint2(id1 | (len1 << 20), id2 | (len2 << 20));
+        if (top.hits == 0u) { top.id1 = idb; top.len1 = 1; }
+        else if (top.hits == 1u) { top.id2 = idb; top.len2 = 1; }
+        M[rel] = make_uint2(top.id1 | (top.len1 << 20), top.id2 | (top.len2 << 20));
     }
 }
 
