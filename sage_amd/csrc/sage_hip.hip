@@ -36,7 +36,7 @@ struct sage_ctx {
     // vocabulary
     DevBuf buckets, keys, byte_id, bloom;
     int match_mode = 0;  // 0 = LDS-filtered persistent matcher, 1 = plain matcher
-    uint32_t bucket_mask = 0;
+    uint32_t bucket_mask = 0, key_plane = 0;
     int max_len = 0;
     int64_t max_id = -1;
     bool have_vocab = false;
@@ -169,7 +169,7 @@ int match_and_count(sage_ctx* c, int64_t line0, int64_t line1, uint64_t* out_tot
     if ((rc = ensure(c, c->occoff, ((size_t)nl + 1) * 4))) return rc;
     if ((rc = ensure(c, c->grand_total, 16))) return rc;
 
-    VocabDev v{c->buckets.as<uint4>(), c->bucket_mask, c->keys.as<uint64_t>(), c->byte_id.as<uint32_t>(),
+    VocabDev v{c->buckets.as<uint4>(), c->bucket_mask, c->keys.as<uint64_t>(), c->key_plane, c->byte_id.as<uint32_t>(),
                c->bloom.as<uint32_t>(), c->max_len};
     if (nb) {
         Prof p(c, SAGE_K_MATCH);
@@ -511,7 +511,8 @@ int sage_set_vocab(sage_ctx* c, const uint8_t* key_bytes, const int64_t* key_off
         max_id = std::max(max_id, id);
     }
     std::vector<uint32_t> byte_id(256, SAGE_SLOT_EMPTY);
-    std::vector<uint64_t> keys((size_t)(max_id + 1) * 4, 0);
+    const size_t key_plane = ((size_t)max_id + 1 + 15) & ~(size_t)15;   // ids per 8-byte-word plane
+    std::vector<uint64_t> keys(key_plane * 4, 0);
     const uint64_t nbuckets = pow2ceil(std::max<uint64_t>(16, (uint64_t)n_keys / 2));  // load factor <= 0.5
     std::vector<uint32_t> slots(nbuckets * 4, SAGE_SLOT_EMPTY);
     std::vector<uint32_t> bloom(SAGE_BLOOM_BITS / 32, 0u);
@@ -520,7 +521,11 @@ int sage_set_vocab(sage_ctx* c, const uint8_t* key_bytes, const int64_t* key_off
         const uint32_t id = (uint32_t)(key_ids ? key_ids[i] : i);
         const uint8_t* k = key_bytes + key_offsets[i];
         const uint32_t len = (uint32_t)(key_offsets[i + 1] - key_offsets[i]);
-        std::memcpy(reinterpret_cast<uint8_t*>(&keys[(size_t)id * 4]), k, len);
+        {
+            uint8_t kb[SAGE_MAX_KEY_LEN] = {0};
+            std::memcpy(kb, k, len);
+            for (int w = 0; w < 4; ++w) std::memcpy(&keys[(size_t)w * key_plane + id], kb + 8 * w, 8);
+        }
         if (len == 1) { byte_id[k[0]] = id; continue; }  // single bytes are looked up directly
         uint32_t h = SAGE_FNV_OFFSET;
         for (uint32_t j = 0; j < len; ++j) h = sage_fnv_step(h, k[j]);
@@ -554,6 +559,7 @@ int sage_set_vocab(sage_ctx* c, const uint8_t* key_bytes, const int64_t* key_off
     HIP_TRY(c, hipMemcpy(c->byte_id.p, byte_id.data(), 256 * 4, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->bloom.p, bloom.data(), bloom.size() * 4, hipMemcpyHostToDevice));
     c->bucket_mask = bmask;
+    c->key_plane = (uint32_t)key_plane;
     c->max_len = max_len;
     c->max_id = max_id;
     c->have_vocab = true;

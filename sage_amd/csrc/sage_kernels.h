@@ -8,7 +8,9 @@
 struct VocabDev {
     const uint4* buckets;     // nbuckets * 4 slots
     uint32_t bucket_mask;     // nbuckets - 1
-    const uint64_t* keys;     // [id][4] zero-padded key bytes, little-endian words
+    const uint64_t* keys;     // [word][id] zero-padded key bytes as little-endian 8-byte words, one plane per word:
+                              // keys of <= 8 bytes (most matches) touch plane 0 only, 16 keys per 128-B line
+    uint32_t key_plane;       // ids per plane
     const uint32_t* byte_id;  // id of each single-byte key
     const uint32_t* bloom;    // SAGE_BLOOM_BITS-bit presence filter over (length, bytes), two bits per key
     int max_len;
@@ -101,14 +103,13 @@ __global__ __launch_bounds__(256) void k_match(const uint8_t* __restrict__ corpu
             for (int q = 0; q < 4; ++q) {
                 if (!hit && slot[q] != SAGE_SLOT_EMPTY && (slot[q] >> 20) == want[j]) {
                     const uint32_t cand = slot[q] & SAGE_ID_MASK;
-                    const uint64_t* key = v.keys + (size_t)cand * 4;
                     bool same = true;
 #pragma unroll
                     for (int w = 0; w < NW; ++w) {
                         const int nb = j - 8 * w;
                         if (nb > 0) {
                             const uint64_t mask = nb >= 8 ? ~0ull : ((1ull << (8 * nb)) - 1ull);
-                            same = same && ((W[w] & mask) == key[w]);
+                            same = same && ((W[w] & mask) == v.keys[(size_t)w * v.key_plane + cand]);
                         }
                     }
                     if (same) { hit = true; hid = cand; }
@@ -144,6 +145,14 @@ __device__ __forceinline__ bool key_equal(const uint64_t (&W)[NW], const uint64_
     }
     return same;
 }
+// the same against the key planes in memory
+template <int NW>
+__device__ __forceinline__ bool key_equal_mem(const VocabDev& v, const uint64_t (&W)[NW], uint32_t id, int j) {
+    uint64_t K[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) K[w] = (j - 8 * w > 0) ? v.keys[(size_t)w * v.key_plane + id] : 0ull;
+    return key_equal<NW>(W, K, j);
+}
 
 // exact serial probe of one length (any bucket chain length, any number of tag collisions)
 template <int NW>
@@ -156,7 +165,7 @@ __device__ __forceinline__ bool probe_exact(const VocabDev& v, uint32_t b, uint3
         for (int q = 0; q < 4; ++q) {
             if (slot[q] != SAGE_SLOT_EMPTY && (slot[q] >> 20) == want) {
                 const uint32_t cnd = slot[q] & SAGE_ID_MASK;
-                if (key_equal<NW>(W, v.keys + (size_t)cnd * 4, j)) { hid = cnd; return true; }
+                if (key_equal_mem<NW>(v, W, cnd, j)) { hid = cnd; return true; }
             }
         }
         if (s.w == SAGE_SLOT_EMPTY) return false;
@@ -202,10 +211,10 @@ __device__ __forceinline__ void probe_chunk(const VocabDev& v, uint32_t cand, co
     uint64_t K[N][NW];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const uint64_t* key = v.keys + (size_t)(have[i] ? cid[i] : 0u) * 4;
+        const uint64_t* key = v.keys + (have[i] ? cid[i] : 0u);
 #pragma unroll
         for (int w = 0; w < NW; ++w)
-            if (JLO + i - 8 * w > 0) K[i][w] = key[w];
+            if (JLO + i - 8 * w > 0) K[i][w] = key[(size_t)w * v.key_plane];
     }
     uint32_t hitm = 0, slow = 0;
 #pragma unroll
@@ -238,26 +247,42 @@ template <int NW>
 __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ corpus, const uint8_t* __restrict__ rem,
                                                     int64_t pos0, uint32_t count, VocabDev v, uint2* __restrict__ M) {
     constexpr int ML = 8 * NW;
-    constexpr int NDW = (1024 + ML + 8) / 4 + 1;
+    constexpr int WDW = (64 + ML + 8) / 4 + 1;   // dwords of text one wave stages for its 64 positions (<= 27)
     __shared__ uint32_t bloom[SAGE_BLOOM_BITS / 32];
-    __shared__ uint32_t text[NDW];
+    __shared__ uint32_t text_all[16 * 32];
     const uint32_t tid = threadIdx.x;
     {
         const uint4* src4 = reinterpret_cast<const uint4*>(v.bloom);
         uint4* dst4 = reinterpret_cast<uint4*>(bloom);
         for (uint32_t i = tid; i < SAGE_BLOOM_BITS / 128; i += 1024) dst4[i] = src4[i];
     }
-    const uint32_t n_tiles = (count + 1023u) / 1024u;
-    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int64_t blk0 = pos0 + (int64_t)tile * 1024;
-        const int64_t a0 = blk0 & ~(int64_t)3;
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(corpus + a0);
-        __syncthreads();
-        for (uint32_t i = tid; i < NDW; i += 1024) text[i] = src[i];
-        __syncthreads();
-        const uint32_t rel = tile * 1024u + tid;
+    __syncthreads();
+    // From here on the 16 waves of the block are independent: each sweeps its own 64-byte tiles and stages its text
+    // window in its own LDS strip, so no block barrier puts the waves' memory phases in lockstep.  The next tile's
+    // text and line-remainder bytes are fetched before the current tile is processed.
+    const uint32_t lane = tid & 63u;
+    uint32_t* text = text_all + (tid >> 6) * 32u;
+    const uint32_t n_tiles = (count + 63u) / 64u;
+    const uint32_t stride = gridDim.x * 16u;
+    uint32_t tile = blockIdx.x * 16u + (tid >> 6);
+    uint32_t tw_n = 0, rm_n = 0;
+    auto fetch = [&](uint32_t tl) {
+        const int64_t b0 = pos0 + (int64_t)tl * 64;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(corpus + (b0 & ~(int64_t)3));
+        if (lane < (uint32_t)WDW) tw_n = __builtin_nontemporal_load(src + lane);
+        rm_n = (tl * 64u + lane < count) ? (uint32_t)__builtin_nontemporal_load(rem + b0 + lane) : 0u;
+    };
+    if (tile < n_tiles) fetch(tile);
+    for (; tile < n_tiles; tile += stride) {
+        const int64_t blk0 = pos0 + (int64_t)tile * 64;
+        const uint32_t tw = tw_n, rm = rm_n;
+        if (tile + stride < n_tiles) fetch(tile + stride);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < (uint32_t)WDW) text[lane] = tw;
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t rel = tile * 64u + lane;
         if (rel >= count) continue;
-        const uint32_t o = (uint32_t)(blk0 - a0) + tid;
+        const uint32_t o = (uint32_t)(blk0 & 3) + lane;
         const uint32_t wi = o >> 2, sh = (o & 3u) * 8u;
         uint32_t T[2 * NW];
         {
@@ -267,7 +292,7 @@ __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ 
 #pragma unroll
             for (int i = 0; i < 2 * NW; ++i) T[i] = __funnelshift_r(d[i], d[i + 1], sh);
         }
-        const uint32_t lim = min((uint32_t)rem[blk0 + tid], (uint32_t)v.max_len);
+        const uint32_t lim = min(rm, (uint32_t)v.max_len);
         uint32_t wantf[ML + 1];
         uint32_t bidx[ML + 1];
         uint32_t miss = 0;   // bit (j-1) set when the filter rules length j out
@@ -310,7 +335,9 @@ __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ 
         const uint32_t idb = v.byte_id[T[0] & 0xFFu];
         if (top.hits == 0u) { top.id1 = idb; top.len1 = 1; }
         else if (top.hits == 1u) { top.id2 = idb; top.len2 = 1; }
-        M[rel] = make_uint2(top.id1 | (top.len1 << 20), top.id2 | (top.len2 << 20));
+        // streamed once: keep it out of the way of the table and key planes in L2
+        __builtin_nontemporal_store((uint64_t)(top.id1 | (top.len1 << 20)) | ((uint64_t)(top.id2 | (top.len2 << 20)) << 32),
+                                    reinterpret_cast<uint64_t*>(M + rel));
     }
 }
 
