@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--style", default="en")
     ap.add_argument("--cpu-lines", type=int, default=0, help="lines of the CPU-baseline sample (0 = auto, <0 = skip)")
     ap.add_argument("--batch-mb", type=int, default=0)
+    ap.add_argument("--match-mode", type=int, default=-1, help="matcher variant (development switch)")
     return ap.parse_args()
 
 
@@ -106,6 +107,8 @@ def main():
     eng = HipSage(local_rank)
     if args.batch_mb:
         eng.set_batch_bytes(args.batch_mb << 20)
+    if args.match_mode >= 0:
+        eng.set_match_mode(args.match_mode)
     t_up = time.time()
     eng.set_vocab(vocab, None, args.max_len)
     eng.set_corpus(corpus, offsets)
