@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Summarise gpurun_out/prof (written by profiles/collect.sh) into profiles/<tag>_*: the rocprofv3 kernel stats
+CSV as is, the bench JSON lines, and a per-kernel table of FETCH_SIZE / WRITE_SIZE (KiB as rocprofv3 reports them,
+summed over XCDs, per launch).  FETCH_SIZE on gfx950 counts 64 B per 128-B request for 16-B-per-lane streaming reads
+(MI355X_MICROARCH.md, HBM section), so `fetch_x2` is the figure to compare with byte counts for such kernels."""
+import collections
+import csv
+import json
+import shutil
+import sys
+from pathlib import Path
+
+tag = sys.argv[1]
+src = Path("gpurun_out/prof")
+dst = Path("profiles")
+shutil.copy(src / "kt/run_kernel_stats.csv", dst / f"{tag}_kernel_stats.csv")
+shutil.copy(src / "bench_full.json", dst / f"{tag}_bench_full.json")
+shutil.copy(src / "bench_kt.json", dst / f"{tag}_bench_under_rocprof.json")
+agg = collections.defaultdict(lambda: {"launches": 0, "FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0})
+for name, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    seen = collections.Counter()
+    for r in csv.DictReader(open(src / name / "run_counter_collection.csv")):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        agg[k][counter] += float(r["Counter_Value"])
+        seen[k] += 1
+    for k, n in seen.items():
+        agg[k]["launches"] = n
+rows = []
+for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["FETCH_SIZE"]):
+    n = max(1, a["launches"])
+    rows.append({"kernel": k, "launches": a["launches"], "fetch_GB_per_launch": a["FETCH_SIZE"] * 1024 / n / 1e9,
+                 "fetch_x2_GB_per_launch": 2 * a["FETCH_SIZE"] * 1024 / n / 1e9,
+                 "write_GB_per_launch": a["WRITE_SIZE"] * 1024 / n / 1e9})
+json.dump(rows, open(dst / f"{tag}_pmc_traffic.json", "w"), indent=1)
+for r in rows[:12]:
+    print(f"{r['kernel']:28s} n={r['launches']:3d} fetch={r['fetch_GB_per_launch']:8.2f} GB (x2 {r['fetch_x2_GB_per_launch']:8.2f})"
+          f" write={r['write_GB_per_launch']:7.2f} GB")
