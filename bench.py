@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--style", default="en")
     ap.add_argument("--cpu-lines", type=int, default=0, help="lines of the CPU-baseline sample (0 = auto, <0 = skip)")
     ap.add_argument("--batch-mb", type=int, default=0)
+    ap.add_argument("--score-mode", type=int, default=0, help="0 = float32 row storage where lossless, 1 = float64 storage")
     ap.add_argument("--match-mode", type=int, default=-1, help="matcher variant (development switch)")
     return ap.parse_args()
 
@@ -120,7 +121,6 @@ def main():
         corpus, offsets = synth.make_corpus(args.lines, seed=seed + rank, style=args.style, n_types=n_types,
                                             progress=log)
     log(f"corpus: {len(corpus)} bytes")
-    emb = synth.make_embeddings(len(vocab), args.dim, seed=seed)
     gen_s = time.time() - t_gen
 
     eng = HipSage(local_rank)
@@ -128,9 +128,22 @@ def main():
         eng.set_batch_bytes(args.batch_mb << 20)
     if args.match_mode >= 0:
         eng.set_match_mode(args.match_mode)
+    eng.set_score_mode(args.score_mode)
     t_up = time.time()
     eng.set_vocab(vocab, None, args.max_len)
+    # Embeddings as train_embeddings leaves them (embeddings.py:77-89): float32 word2vec vectors for the tokens the
+    # tokenized corpus contains (word2vec is trained on that very tokenization, min_count=1), the float64 uniform
+    # draw for the rest.  The corpus is tokenized here on the GPU; with several ranks the token counts are summed so
+    # that every rank builds the same matrix.
     eng.set_corpus(corpus, offsets)
+    seen_counts = np.bincount(eng.tokenize(0, len(offsets) - 1)[0], minlength=len(vocab)).astype(np.int64)
+    if world > 1:
+        t = torch.from_numpy(seen_counts).cuda()
+        dist.all_reduce(t)
+        seen_counts = t.cpu().numpy()
+    seen = seen_counts > 0
+    emb = synth.make_embeddings(len(vocab), args.dim, seed=seed, unseen=~seen)
+    log(f"embeddings: {int((~seen).sum())} of {len(vocab)} rows are float64 uniform draws (tokens the corpus never produces)")
     eng.set_embeddings(emb)
     upload_s = time.time() - t_up
     log(f"uploaded in {upload_s:.1f} s")
@@ -183,14 +196,15 @@ def main():
         f_m = st["occurrences"] / tokens_local
         r_bar = st["rows"] / max(1, st["occurrences"])
         p_bar = st["records"] / max(1, st["occurrences"])
-        A = b_bar + 9 + f_m * (r_bar * args.dim * 8 + 16 * p_bar)
+        eb = st["emb_elem_bytes"]   # 4 when the rows are gathered from the lossless float32 copy, else 8
+        A = b_bar + 9 + f_m * (r_bar * args.dim * eb + 16 * p_bar)
         per_kernel_bytes = {   # per step, this rank; DESIGN.md "Kernels" states each figure
             "match": st["corpus_bytes"] * (1 + 1 + 8),
             "walk": st["corpus_bytes"] * 8 / max(1.0, b_bar) * 2 + tokens_local * 8,
             "count": st["records"] * 8 * 2,
-            "score": st["rows"] * args.dim * 8,
+            "score": st["rows"] * args.dim * eb,
             "describe": st["corpus_bytes"] * 8 + tokens_local * (8 + 64),
-            "pairs": tokens_local * (args.dim * 8 + 16),
+            "pairs": tokens_local * (args.dim * eb + 16),
             "logsig": st["pairs"] * 8 + st["occurrences"] * 64,
         }
         dom = max(per_kernel_bytes, key=lambda k: kt[k][0])
@@ -212,7 +226,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{args.lines}-line synthetic {args.style}-wiki-shaped corpus per GPU, single "
+            "config": {"embeddings": f"float32 word2vec-shaped rows upcast to float64, {int((~seen).sum())} float64 uniform rows (embeddings.py:77-89)",
+                       "workload": f"{args.lines}-line synthetic {args.style}-wiki-shaped corpus per GPU, single "
                                    f"{args.vocab}-key vocabulary ablation step (tokenize + score + counts), D={args.dim}, "
                                    f"max_len={args.max_len}, pad=2, workers_number={args.workers}",
                        "lines_per_gpu": args.lines, "vocab": len(vocab), "dim": args.dim, "max_len": args.max_len,
@@ -223,7 +238,8 @@ def main():
                          "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step,
                          "algorithmic_bytes_per_launch": per_kernel_bytes[dom] / launches_per_step},
             "step_roofline": {"bytes_per_token_A": A, "achieved_GBs_per_gpu": step_gbs, "frac": step_gbs / HBM_PEAK_GBS,
-                              "b_bar": b_bar, "f_m": f_m, "r_bar": r_bar, "p_bar": p_bar},
+                              "b_bar": b_bar, "f_m": f_m, "r_bar": r_bar, "p_bar": p_bar, "emb_elem_bytes": eb,
+                              "f64_fix_occurrences": st["f64_fix_occurrences"]},
             "kernel_ms_per_step": {k: kt[k][0] / args.steps for k in kt},
             "setup_s": {"generate": gen_s, "upload": upload_s},
         }

@@ -124,9 +124,18 @@ int sage_set_match_mode(sage_ctx* ctx, int mode);
  * fallback the library takes by itself if an LDS set ever overflows).  Results are identical. */
 int sage_set_count_mode(sage_ctx* ctx, int mode);
 
+/* Storage of the embedding rows on the scoring path (compute_losses, utils.py:125-138; arithmetic is float64 in
+ * both modes).  0 (default): rows whose values are all float32-representable -- every row train_embeddings fills
+ * from word2vec (embeddings.py:81) -- are gathered from a float32 copy (half the bytes; products of two float32
+ * are exact in float64), and every pair that touches another row (the float64 uniform rows of embeddings.py:86) is
+ * recomputed from the float64 matrix; if more than a quarter of the rows are not float32-representable the float64
+ * matrix is used for everything.  1: float64 storage only.  Takes effect at the next sage_set_embeddings. */
+int sage_set_score_mode(sage_ctx* ctx, int mode);
+
 /* Workload statistics of the last step, for the roofline's algorithmic bytes:
  * out[0]=tokens, out[1]=corpus bytes, out[2]=ablated occurrences, out[3]=embedding rows touched,
- * out[4]=signed pair records, out[5]=distinct-count probes inserted. */
+ * out[4]=signed pair records, out[5]=distinct-count probes inserted, out[6]=bytes per stored embedding element on
+ * the main scoring pass (4 or 8), out[7]=occurrences recomputed from the float64 matrix. */
 int sage_get_step_stats(sage_ctx* ctx, int64_t* out /*[8]*/);
 
 #ifdef __cplusplus

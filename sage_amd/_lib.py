@@ -67,6 +67,8 @@ def load():
     lib.sage_set_batch_bytes.argtypes = [vp, i64]
     lib.sage_set_match_mode.restype = C.c_int
     lib.sage_set_match_mode.argtypes = [vp, C.c_int]
+    lib.sage_set_score_mode.restype = C.c_int
+    lib.sage_set_score_mode.argtypes = [vp, C.c_int]
     lib.sage_set_count_mode.restype = C.c_int
     lib.sage_set_count_mode.argtypes = [vp, C.c_int]
     lib.sage_get_step_stats.restype = C.c_int
@@ -78,7 +80,7 @@ def load():
 EXPORTED = ["sage_version", "sage_create", "sage_destroy", "sage_last_error", "sage_set_vocab", "sage_set_corpus",
             "sage_set_embeddings", "sage_tokenize", "sage_ablation_step", "sage_ablation_step_device",
             "sage_set_profiling", "sage_reset_kernel_times", "sage_get_kernel_times", "sage_set_batch_bytes",
-            "sage_set_match_mode", "sage_set_count_mode", "sage_get_step_stats"]
+            "sage_set_match_mode", "sage_set_count_mode", "sage_set_score_mode", "sage_get_step_stats"]
 
 
 class HipSage:
@@ -203,8 +205,13 @@ class HipSage:
     def set_count_mode(self, mode: int):
         self._check(self._lib.sage_set_count_mode(self._h, int(mode)))
 
+    def set_score_mode(self, mode: int):
+        """0 = float32 row storage where lossless (default), 1 = float64 storage; call before set_embeddings."""
+        self._check(self._lib.sage_set_score_mode(self._h, int(mode)))
+
     def step_stats(self):
         out = np.zeros(8, dtype=np.int64)
         self._check(self._lib.sage_get_step_stats(self._h, _ptr(out, C.c_int64)))
         return {"tokens": int(out[0]), "corpus_bytes": int(out[1]), "occurrences": int(out[2]),
-                "rows": int(out[3]), "records": int(out[4]), "pairs": int(out[5])}
+                "rows": int(out[3]), "records": int(out[4]), "pairs": int(out[5]), "emb_elem_bytes": int(out[6]),
+                "f64_fix_occurrences": int(out[7])}

@@ -61,6 +61,7 @@ SAGE_HD uint64_t sage_mix64(uint64_t k) {
 #define SAGE_DH_VALID 0x80000000u
 #define SAGE_DH_OVER 0x40000000u
 #define SAGE_DH_NEVER 0x20000000u
+#define SAGE_DH_INEXACT 0x10000000u  // the ablated window holds a row whose values are not float32-representable
 #define SAGE_DH_K(h) ((h) & 0xFFFu)
 #define SAGE_DH_M(h) (((h) >> 12) & 0xFFFu)
 #define SAGE_DH_PL(h) (((h) >> 24) & 3u)

@@ -48,10 +48,15 @@ struct sage_ctx {
     bool have_corpus = false;
 
     // embeddings
-    DevBuf emb;
-    int64_t emb_rows = 0;
+    DevBuf emb;           // float64 rows (always kept: the exact values)
+    DevBuf emb32;         // float32 rows, when most rows are float32-representable (word2vec output is)
+    DevBuf inexact;       // bitmap of the rows that are not: their pairs are recomputed from `emb`
+    DevBuf inex_list, inex_count;
+    int64_t emb_rows = 0, n_inexact = 0;
     int dim = 0, dp = 0;
     bool have_emb = false;
+    bool use_f32 = false;
+    int score_mode = 0;   // 0 = float32 storage when lossless for most rows, 1 = always float64 storage
 
     // scratch (grow-only; nothing is allocated in the steady state)
     DevBuf M, ntok, tokoff, tile_sums, grand_total, tok_w0, tok_pos, set, seg_line_rel, seg_tok_off, set_base, set_mask, seg_pairs, desc, gcache, hist1, bucket_off, rec_a, rec_b,
@@ -227,21 +232,55 @@ int padded_dim(int dim) {
     return 0;
 }
 
-template <int G, int EPL>
-void launch_score(sage_ctx* c, const uint32_t* tok_w0, uint32_t n_tok, uint32_t n_occ) {
-    const uint32_t gpb = 256 / G;
+template <int G, int EPL, int GD, int EPLD, typename T>
+void launch_pairs_dots(sage_ctx* c, const T* emb, const uint32_t* tok_w0, uint32_t n_tok, uint32_t n_occ, bool fix) {
+    // G x EPL = lanes per row x elements per lane of the pair cache, GD x EPLD of the window dots
+    const uint32_t* bitmap = c->inexact.as<uint32_t>();
     {
         Prof p(c, SAGE_K_PAIRS);
-        const uint32_t grid = std::min<uint32_t>(cdiv(cdiv(n_tok, 4), gpb), 256u * 16u);
-        k_pair_cache<G, EPL><<<grid, 256, 0, c->stream>>>(tok_w0, n_tok, c->emb.as<double>(), (uint32_t)c->emb_rows,
-                                                          (uint32_t)c->dp, c->gcache.as<double2>(), c->flags.as<uint32_t>());
+        const uint32_t grid = std::min<uint32_t>(cdiv(cdiv(n_tok, 4), 256 / G), 256u * 16u);
+        if (fix)
+            k_pair_cache<G, EPL, T, true><<<grid, 256, 0, c->stream>>>(tok_w0, n_tok, emb, (uint32_t)c->emb_rows, (uint32_t)c->dp,
+                                                                       c->gcache.as<double2>(), c->flags.as<uint32_t>(), bitmap);
+        else
+            k_pair_cache<G, EPL, T, false><<<grid, 256, 0, c->stream>>>(tok_w0, n_tok, emb, (uint32_t)c->emb_rows, (uint32_t)c->dp,
+                                                                        c->gcache.as<double2>(), c->flags.as<uint32_t>(), nullptr);
     }
     {
         Prof p(c, SAGE_K_SCORE);
-        const uint32_t grid = std::min<uint32_t>(cdiv(n_occ, gpb), (uint32_t)c->n_cu * 4u);
-        k_dots<G, EPL><<<grid, 256, 0, c->stream>>>(c->desc.as<uint4>(), c->pool.as<uint32_t>(), n_occ,
-                                                    c->dot_off.as<uint32_t>(), c->emb.as<double>(), (uint32_t)c->emb_rows,
-                                                    (uint32_t)c->dp, c->dots.as<double>(), c->flags.as<uint32_t>());
+        const uint32_t grid = std::min<uint32_t>(cdiv(n_occ, 256 / GD), (uint32_t)c->n_cu * (sizeof(T) == 4 ? 5u : 4u));
+        k_dots<GD, EPLD, T, 5><<<grid, 256, 0, c->stream>>>(
+            c->desc.as<uint4>(), c->pool.as<uint32_t>(), n_occ, c->dot_off.as<uint32_t>(), emb, (uint32_t)c->emb_rows,
+            (uint32_t)c->dp, c->dots.as<double>(), c->flags.as<uint32_t>(),
+            fix ? c->inex_list.as<uint32_t>() : nullptr, fix ? c->inex_count.as<uint32_t>() : nullptr);
+    }
+}
+
+// pair cache + window dots (float32 rows first and a float64 pass over the flagged occurrences, or float64 only),
+// then the log-sigmoid reduction
+void launch_score(sage_ctx* c, const uint32_t* tok_w0, uint32_t n_tok, uint32_t n_occ) {
+    const double* e64 = c->emb.as<double>();
+    const float* e32 = c->emb32.as<float>();
+    const bool fix = c->use_f32 && c->n_inexact > 0;
+    if (c->use_f32) {
+        switch (c->dp) {
+        case 32: launch_pairs_dots<8, 4, 8, 4>(c, e32, tok_w0, n_tok, n_occ, false); break;
+        case 64: launch_pairs_dots<8, 8, 8, 8>(c, e32, tok_w0, n_tok, n_occ, false); break;
+        case 128: launch_pairs_dots<16, 8, 16, 8>(c, e32, tok_w0, n_tok, n_occ, false); break;
+        case 256: launch_pairs_dots<32, 8, 32, 8>(c, e32, tok_w0, n_tok, n_occ, false); break;
+        case 384: launch_pairs_dots<32, 12, 32, 12>(c, e32, tok_w0, n_tok, n_occ, false); break;
+        default: launch_pairs_dots<64, 8, 64, 8>(c, e32, tok_w0, n_tok, n_occ, false); break;
+        }
+    }
+    if (!c->use_f32 || fix) {
+        switch (c->dp) {
+        case 32: launch_pairs_dots<8, 4, 8, 4>(c, e64, tok_w0, n_tok, n_occ, fix); break;
+        case 64: launch_pairs_dots<8, 8, 8, 8>(c, e64, tok_w0, n_tok, n_occ, fix); break;
+        case 128: launch_pairs_dots<16, 8, 16, 8>(c, e64, tok_w0, n_tok, n_occ, fix); break;
+        case 256: launch_pairs_dots<32, 8, 32, 8>(c, e64, tok_w0, n_tok, n_occ, fix); break;
+        case 384: launch_pairs_dots<64, 6, 64, 6>(c, e64, tok_w0, n_tok, n_occ, fix); break;
+        default: launch_pairs_dots<64, 8, 64, 8>(c, e64, tok_w0, n_tok, n_occ, fix); break;
+        }
     }
     {
         Prof p(c, SAGE_K_LOGSIG);
@@ -332,6 +371,12 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
             if ((rc = ensure(c, c->pool, pool_cap * 4))) return rc;
             HIP_TRY(c, hipMemsetAsync(c->seg_pairs.p, 0, (size_t)nsb * 8, c->stream));
             HIP_TRY(c, hipMemsetAsync(c->pool_cursor.p, 0, 4, c->stream));
+            const bool fix_pass = c->use_f32 && c->n_inexact > 0;
+            if (fix_pass) {
+                if ((rc = ensure(c, c->inex_list, (size_t)n_occ * 4))) return rc;
+                if ((rc = ensure(c, c->inex_count, 4))) return rc;
+                HIP_TRY(c, hipMemsetAsync(c->inex_count.p, 0, 4, c->stream));
+            }
             SegPlan S{c->seg_tok_off.as<uint32_t>(), c->set_base.as<uint64_t>(), c->set_mask.as<uint64_t>(), nsb};
             const uint32_t cgrid = std::min<uint32_t>(cdiv(n_occ, 256), 256u * 16u);
             {
@@ -341,7 +386,8 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
                     c->pool.as<uint32_t>(), c->pool_cursor.as<uint32_t>(), (uint32_t)pool_cap,
                     c->seg_pairs.as<unsigned long long>(), c->occ.as<unsigned long long>(),
                     c->hist.as<unsigned long long>(), (uint32_t)hist_len, c->stats.as<unsigned long long>(),
-                    c->flags.as<uint32_t>());
+                    c->flags.as<uint32_t>(), fix_pass ? c->inexact.as<uint32_t>() : nullptr,
+                    c->inex_list.as<uint32_t>(), c->inex_count.as<uint32_t>());
             }
             // offsets of every occurrence's ablated-window dots; grand_total[1] is reused for the dot total
             if ((rc = scan_u32(c, c->np_ab.as<uint32_t>(), n_occ, c->dot_off.as<uint32_t>(), c->grand_total.as<uint64_t>() + 1))) return rc;
@@ -410,14 +456,7 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
             }
             if (n_dots >= 0xFFFFFF00ull) return fail(c, SAGE_E_LIMIT, "a batch must stay under 2^32 ablated-window pairs");
             if ((rc = ensure(c, c->dots, std::max<uint64_t>(n_dots, 1) * 8))) return rc;
-            switch (c->dp) {
-            case 32: launch_score<8, 4>(c, A.tok_w0, n_tok, n_occ); break;
-            case 64: launch_score<8, 8>(c, A.tok_w0, n_tok, n_occ); break;
-            case 128: launch_score<16, 8>(c, A.tok_w0, n_tok, n_occ); break;
-            case 256: launch_score<32, 8>(c, A.tok_w0, n_tok, n_occ); break;
-            case 384: launch_score<64, 6>(c, A.tok_w0, n_tok, n_occ); break;
-            default: launch_score<64, 8>(c, A.tok_w0, n_tok, n_occ); break;
-            }
+            launch_score(c, A.tok_w0, n_tok, n_occ);
             HIP_TRY(c, hipGetLastError());
             sa = sb;
         }
@@ -449,6 +488,8 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
         c->step_stats[3] = (int64_t)stats[STAT_ROWS];
         c->step_stats[4] = (int64_t)stats[STAT_PAIRS] * 2;   // signed (t,c) records: both orders
         c->step_stats[5] = (int64_t)stats[STAT_PAIRS];
+        c->step_stats[6] = c->use_f32 ? 4 : 8;   // bytes per stored embedding element on the main scoring pass
+        c->step_stats[7] = (int64_t)stats[STAT_INEXACT];
         return SAGE_OK;
     }
 }
@@ -488,7 +529,7 @@ void sage_destroy(sage_ctx* c) {
     DevBuf* all[] = {&c->buckets, &c->keys, &c->byte_id, &c->bloom, &c->corpus, &c->rem, &c->line_off, &c->emb, &c->M, &c->ntok,
                      &c->tokoff, &c->tile_sums, &c->grand_total, &c->tok_w0, &c->tok_pos, &c->set, &c->seg_line_rel,
                      &c->seg_tok_off, &c->set_base, &c->set_mask, &c->seg_pairs, &c->desc, &c->gcache, &c->hist1, &c->bucket_off, &c->rec_a, &c->rec_b, &c->nocc, &c->occoff, &c->occ_tok,
-                     &c->np_ab, &c->dot_off, &c->dots, &c->pool, &c->pool_cursor, &c->ex_ids, &c->ex_starts, &c->ex_widths, &c->loss,
+                     &c->np_ab, &c->dot_off, &c->dots, &c->pool, &c->pool_cursor, &c->emb32, &c->inexact, &c->inex_list, &c->inex_count, &c->ex_ids, &c->ex_starts, &c->ex_widths, &c->loss,
                      &c->occ, &c->hist, &c->stats, &c->flags};
     for (DevBuf* b : all) release(*b);
     (void)hipStreamDestroy(c->stream);
@@ -610,6 +651,29 @@ int sage_set_embeddings(sage_ctx* c, const double* emb, int64_t rows, int32_t di
     c->emb_rows = rows;
     c->dim = dim;
     c->dp = dp;
+    // float32 copy + bitmap of the rows it does not represent exactly (embeddings.py:81 fills rows from float32
+    // word2vec vectors, embeddings.py:86 fills the rest from a float64 uniform draw)
+    std::vector<float> e32((size_t)rows * dp, 0.0f);
+    std::vector<uint32_t> bitmap(((size_t)rows + 31) / 32 + 1, 0u);
+    int64_t n_inexact = 0;
+    for (int64_t r = 0; r < rows; ++r) {
+        const double* src = emb + (size_t)r * dim;
+        float* dst = e32.data() + (size_t)r * dp;
+        bool exact = true;
+        for (int d = 0; d < dim; ++d) {
+            dst[d] = (float)src[d];
+            exact = exact && ((double)dst[d] == src[d]);   // false for NaN: such rows keep their float64 form
+        }
+        if (!exact) { bitmap[(size_t)r >> 5] |= 1u << (r & 31); ++n_inexact; }
+    }
+    c->n_inexact = n_inexact;
+    c->use_f32 = (c->score_mode == 0 && n_inexact * 4 <= rows) || (c->score_mode == 2 && n_inexact < rows);
+    if (c->use_f32) {
+        if ((rc = ensure(c, c->emb32, e32.size() * 4))) return rc;
+        if ((rc = ensure(c, c->inexact, bitmap.size() * 4))) return rc;
+        HIP_TRY(c, hipMemcpy(c->emb32.p, e32.data(), e32.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->inexact.p, bitmap.data(), bitmap.size() * 4, hipMemcpyHostToDevice));
+    }
     c->have_emb = true;
     return SAGE_OK;
 }
@@ -722,6 +786,13 @@ int sage_set_batch_bytes(sage_ctx* c, int64_t bytes) {
 int sage_set_match_mode(sage_ctx* c, int mode) {
     if (!c || (mode != 0 && mode != 1)) return fail(c, SAGE_E_ARG, "match mode must be 0 or 1");
     c->match_mode = mode;
+    return SAGE_OK;
+}
+
+int sage_set_score_mode(sage_ctx* c, int mode) {
+    if (!c || mode < 0 || mode > 2) return fail(c, SAGE_E_ARG, "score mode must be 0, 1 or 2");
+    c->score_mode = mode;
+    c->have_emb = false;   // takes effect at the next sage_set_embeddings
     return SAGE_OK;
 }
 

@@ -65,6 +65,10 @@ __device__ __forceinline__ uint32_t win_ablated_pairs(uint32_t pl, uint32_t k, u
     return n;                                            // (a left and a right pad are never within 2 of each other: k >= 2)
 }
 
+#ifndef SAGE_NI
+#define SAGE_NI 2   // window ids in flight in front of the row ring of k_dots
+#endif
+
 // ----------------------------------------------------------------------------------------------------------
 // k_describe: one thread per ablated occurrence walks it (model.py:168-232) once.
 //   -> descriptor, ablated_sizes histogram, occurrences per id, position pairs per count segment, number of
@@ -76,7 +80,9 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
                                                   uint32_t pool_cap, unsigned long long* __restrict__ seg_pairs,
                                                   unsigned long long* __restrict__ occ,
                                                   unsigned long long* __restrict__ hist, uint32_t hist_len,
-                                                  unsigned long long* __restrict__ stats, uint32_t* __restrict__ flags) {
+                                                  unsigned long long* __restrict__ stats, uint32_t* __restrict__ flags,
+                                                  const uint32_t* __restrict__ inexact, uint32_t* __restrict__ inex_list,
+                                                  uint32_t* __restrict__ inex_count) {
     __shared__ uint32_t rows[256 * DESC_LDS_STRIDE];
     __shared__ unsigned int lhist[32];
     __shared__ uint32_t occ_id[ACC_SLOTS];
@@ -93,6 +99,7 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
         const uint32_t t = live ? occ_tok[o] : 0u;
         const uint32_t seg = live ? find_segment(S, t) : 0xFFFFFFFFu;
         unsigned long long my_pairs = 0;
+        uint32_t inex = 0;   // a row of the ablated window is flagged in the `inexact` bitmap (float32 fast path only)
         if (live) {
             Walker w;
             w.init(A, t);
@@ -107,6 +114,7 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
                 if (!base_window) {
                     ++n_rows;
                     if (L < SAGE_DESC_MAXWIN) my[1 + L] = id;
+                    if (inexact) inex |= (inexact[id >> 5] >> (id & 31u)) & 1u;
                     ++L;
                     ab_pairs += np;
                 } else if (c) {
@@ -116,7 +124,8 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
                 c2 = c1; c1 = c; ++have;
             }
             const bool pooled = L > SAGE_DESC_MAXWIN || m > 0xFFFu;
-            uint32_t hdr = SAGE_DH_VALID | (w.never ? SAGE_DH_NEVER : 0u) | ((uint32_t)w.pl << 24) | ((uint32_t)w.pr << 26);
+            uint32_t hdr = SAGE_DH_VALID | (w.never ? SAGE_DH_NEVER : 0u) | ((uint32_t)w.pl << 24) | ((uint32_t)w.pr << 26) |
+                           (inex ? SAGE_DH_INEXACT : 0u);
             if (!pooled) {
                 hdr |= w.k | (m << 12);
             } else {
@@ -142,6 +151,19 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
             if (kk < 32u) atomicAdd(&lhist[kk], 1u); else atomicAdd(&hist[kk], 1ull);
         }
         n_pairs += my_pairs;
+        if (inexact) {   // flagged occurrences go on a list for the float64 fix-up pass (one atomic per wave)
+            const unsigned long long bal = __ballot(inex != 0u);
+            if (bal) {
+                const uint32_t lane = threadIdx.x & 63u;
+                uint32_t at = 0;
+                if (lane == (uint32_t)__ffsll((long long)bal) - 1u) {
+                    at = atomicAdd(inex_count, (uint32_t)__popcll(bal));
+                    atomicAdd(&stats[STAT_INEXACT], (unsigned long long)__popcll(bal));
+                }
+                at = __shfl(at, __ffsll((long long)bal) - 1, 64);
+                if (inex) inex_list[at + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = o;
+            }
+        }
         {   // pairs per segment: one atomic per wave when the wave sits inside one segment (the usual case)
             const uint32_t seg0 = __shfl(seg, 0, 64);
             if (__all(seg == seg0 || seg == 0xFFFFFFFFu) && seg0 != 0xFFFFFFFFu) {
@@ -193,6 +215,19 @@ __device__ __forceinline__ void load_row_slice(const double* __restrict__ emb, u
         r[2 * i] = v.x; r[2 * i + 1] = v.y;
     }
 }
+// float32 storage (lossless for word2vec vectors, which are float32 upcast to float64: embeddings.py:81): the slice
+// stays float32 in registers while in flight -- half the registers and half the bytes of the float64 form.
+template <int G, int EPL>
+__device__ __forceinline__ void load_row_slice(const float* __restrict__ emb, uint32_t id, uint32_t dp, uint32_t gl,
+                                               float (&r)[EPL]) {
+    static_assert(EPL % 4 == 0, "float slices are whole 16-byte loads");
+    const float4* row = reinterpret_cast<const float4*>(emb + (size_t)id * dp) + gl;
+#pragma unroll
+    for (int i = 0; i < EPL / 4; ++i) {
+        const float4 v = row[(size_t)G * i];
+        r[4 * i] = v.x; r[4 * i + 1] = v.y; r[4 * i + 2] = v.z; r[4 * i + 3] = v.w;
+    }
+}
 // Sum over the G lanes of a group, result in every lane.  The first levels are DPP moves inside a 16-lane row
 // (quad_perm xor 1, xor 2, row_half_mirror, row_mirror): VALU only, no trip through the LDS crossbar.
 __device__ __forceinline__ double dpp_add(double v, const int ctrl_sel) {
@@ -210,18 +245,27 @@ template <int G>
 __device__ __forceinline__ double group_sum(double d) {
     d = dpp_add(d, 0);
     d = dpp_add(d, 1);
-    d = dpp_add(d, 2);
+    if (G >= 8) d = dpp_add(d, 2);
     if (G >= 16) d = dpp_add(d, 3);
 #pragma unroll
     for (int m = 16; m < G; m <<= 1) d += __shfl_xor(d, m, G);
     return d;
 }
-template <int G, int EPL>
-__device__ __forceinline__ double group_dot(const double (&a)[EPL], const double (&b)[EPL]) {
+// float64 accumulation in both forms; the product of two float32 values is exact in float64
+template <int G, int EPL, typename T>
+__device__ __forceinline__ double group_dot(const T (&a)[EPL], const T (&b)[EPL]) {
     double d = 0.0;
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) d = fma(a[e], b[e], d);
+    for (int e = 0; e < EPL; ++e) d = fma((double)a[e], (double)b[e], d);
     return group_sum<G>(d);
+}
+// OR of a predicate over the G lanes of a group
+template <int G>
+__device__ __forceinline__ bool group_any(bool p) {
+    const unsigned long long bal = __ballot(p);
+    if (G >= 64) return bal != 0ull;
+    const uint32_t base = (threadIdx.x & 63u) & ~(uint32_t)(G - 1);
+    return ((bal >> base) & ((1ull << (G & 63)) - 1ull)) != 0ull;
 }
 
 // ----------------------------------------------------------------------------------------------------------
@@ -230,18 +274,20 @@ __device__ __forceinline__ double group_dot(const double (&a)[EPL], const double
 // do_triples), so base rows are gathered once per token, not once per occurrence.
 // A group of G lanes owns 4 consecutive tokens: 6 rows, 8 dots, one log-sigmoid per lane.
 // ----------------------------------------------------------------------------------------------------------
-template <int G, int EPL>
+template <int G, int EPL, typename T, bool FIX>
 __global__ __launch_bounds__(256) void k_pair_cache(const uint32_t* __restrict__ tok_w0, uint32_t n_tok,
-                                                    const double* __restrict__ emb, uint32_t emb_rows, uint32_t dp,
-                                                    double2* __restrict__ Gc, uint32_t* __restrict__ flags) {
+                                                    const T* __restrict__ emb, uint32_t emb_rows, uint32_t dp,
+                                                    double2* __restrict__ Gc, uint32_t* __restrict__ flags,
+                                                    const uint32_t* __restrict__ inexact) {
+    // FIX: the float64 fix-up pass of the float32 fast path -- only quads that touch a flagged row are recomputed
     const uint32_t gl = threadIdx.x % G;
     const uint32_t groups_per_block = 256 / G;
     const uint32_t n_quads = (n_tok + 3u) / 4u;
     for (uint32_t q0 = blockIdx.x * groups_per_block; q0 < n_quads; q0 += gridDim.x * groups_per_block) {
         const uint32_t quad = q0 + threadIdx.x / G;
         const uint32_t i0 = quad * 4u;
-        double r[6][EPL];
-        uint32_t after[4];
+        T r[6][EPL];
+        uint32_t after[4], ids[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const uint32_t i = i0 + j;
@@ -249,14 +295,23 @@ __global__ __launch_bounds__(256) void k_pair_cache(const uint32_t* __restrict__
             if (j < 4) after[j] = i < n_tok ? SAGE_T_AFTER3(w) : 0u;
             uint32_t id = SAGE_T_ID(w);
             if (id >= emb_rows) { if (i < n_tok) flags[FLAG_ROW_OOB] = 1; id = 0; }
-            load_row_slice<G, EPL>(emb, id, dp, gl, r[j]);
+            ids[j] = id;
         }
+        if (FIX) {
+            uint32_t mine_id = ids[0];
+#pragma unroll
+            for (int j = 1; j < 6; ++j) mine_id = ((int)gl == j) ? ids[j] : mine_id;
+            const bool flagged = gl < 6u && ((inexact[mine_id >> 5] >> (mine_id & 31u)) & 1u);
+            if (!group_any<G>(flagged)) continue;
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) load_row_slice<G, EPL>(emb, ids[j], dp, gl, r[j]);
         double mine = 0.0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
 #pragma unroll
             for (int s = 1; s <= 2; ++s) {
-                const double d = group_dot<G, EPL>(r[j], r[j + s]);
+                const double d = group_dot<G, EPL, T>(r[j], r[j + s]);
                 if ((int)gl == 2 * j + (s - 1)) mine = d;
             }
         }
@@ -277,84 +332,96 @@ __global__ __launch_bounds__(256) void k_pair_cache(const uint32_t* __restrict__
 // flight while row j is reduced, the next occurrence's header is loaded one occurrence ahead, and there is no
 // barrier, no LDS and no transcendental code in this kernel, so a CU keeps >100 KB of row gathers outstanding.
 // ----------------------------------------------------------------------------------------------------------
-struct DotTask {          // fetch-side state of one lane group
-    uint32_t o;           // occurrence index
-    uint32_t j, L, pl, k; // next element to fetch, window geometry
-    const uint32_t* ids;  // window ids (descriptor words or pool)
-};
-
-template <int G, int EPL>
+template <int G, int EPL, typename T, int NS>
 __global__ __launch_bounds__(256) void k_dots(const uint4* __restrict__ desc, const uint32_t* __restrict__ pool,
                                               uint32_t n_occ, const uint32_t* __restrict__ dot_off,
-                                              const double* __restrict__ emb, uint32_t emb_rows, uint32_t dp,
-                                              double* __restrict__ dots, uint32_t* __restrict__ flags) {
+                                              const T* __restrict__ emb, uint32_t emb_rows, uint32_t dp,
+                                              double* __restrict__ dots, uint32_t* __restrict__ flags,
+                                              const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count) {
+    // list != nullptr: only the *list_count occurrences on the list are processed (float64 fix-up pass of the float32
+    // fast path)
     const uint32_t gl = threadIdx.x % G;
     const uint32_t n_groups = gridDim.x * (256u / G);
     const uint32_t gid = blockIdx.x * (256u / G) + threadIdx.x / G;
+    const uint32_t n = list ? *list_count : n_occ;
     // Each element travelling through the pipeline carries: its row slice and a meta word
     //   bit0: dot with the previous element, bit1: dot with the one before, bit2: first element of an occurrence,
     //   bit3: element exists.  `out` is only read at a first element.
-    double B0[EPL], B1[EPL], B2[EPL], B3[EPL], B4[EPL];   // ring of row slices; roles rotate, data never moves
-    uint32_t m0 = 0, ma = 0, mb = 0, outa = 0, outb = 0, out0 = 0;
-    // fetch side
-    uint32_t fo = gid, fj = 0, fL = 0, fpl = 0, fk = 0;
+    // Ring of NS row slices; roles rotate, data never moves: the current row, the two before it, and NF = NS - 3 rows
+    // whose loads are in flight (fully unrolled: every index below is a compile-time constant).  In front of the rows
+    // runs a queue of NI window ids whose loads are in flight, so the dependent chain id -> row address -> row never
+    // stalls a step: an element enters as an id load, NI steps later its row load is issued, NF steps later it is
+    // reduced against its two predecessors.
+    constexpr int NF = NS - 3, NI = SAGE_NI, NQ = NF + NI;
+    static_assert(NF >= 1, "ring too short");
+    T B[NS][EPL];
+    uint32_t qid[NI];           // ids in flight, oldest first
+    uint32_t qm[NQ], qo[NQ];    // meta / output offset of every element in flight (rows first, then ids), oldest first
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) { qm[i] = 0; qo[i] = 0; }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) qid[i] = 0;
+    // id side: fi = position (in the list, or plain index) of the next occurrence to open, foi = its index,
+    // nh = its header words (prefetched one occurrence ahead)
+    uint32_t fi = gid, foi = 0, fj = 0, fL = 0, fpl = 0, fk = 0;
     const uint32_t* fids = nullptr;
-    uint4 nh = make_uint4(0, 0, 0, 0);            // header words of occurrence `fo` (prefetched)
-    if (fo < n_occ) nh = desc[(size_t)fo * 4];
-    bool f_more = fo < n_occ;
-    auto fetch = [&](double (&dst)[EPL], uint32_t& meta, uint32_t& out) {
-        meta = 0;
-        if (!f_more) return;
-        if (fj == fL) {   // open occurrence fo from the prefetched header, prefetch the next header
+    uint4 nh = make_uint4(0, 0, 0, 0);
+    if (fi < n) { foi = list ? list[fi] : fi; nh = desc[(size_t)foi * 4]; }
+    auto fetch_id = [&](uint32_t& id, uint32_t& meta, uint32_t& out) {
+        meta = 0; id = 0;
+        if (fj == fL) {   // open the next occurrence from the prefetched header, prefetch the one after
+            if (fi >= n) return;
             const Win w = win_decode(nh.x, nh.z, nh.w);
             fL = w.L; fpl = w.pl; fk = w.k; fj = 0;
-            fids = w.pooled ? pool + nh.y : reinterpret_cast<const uint32_t*>(desc + (size_t)fo * 4) + 1;
-            out = dot_off[fo];
-            const uint32_t nxt = fo + n_groups;
-            if (nxt < n_occ) nh = desc[(size_t)nxt * 4];
+            fids = w.pooled ? pool + nh.y : reinterpret_cast<const uint32_t*>(desc + (size_t)foi * 4) + 1;
+            out = dot_off[foi];
+            fi += n_groups;
+            if (fi < n) { foi = list ? list[fi] : fi; nh = desc[(size_t)foi * 4]; }
         }
-        uint32_t id = fids[fj];
-        if (id >= emb_rows) { flags[FLAG_ROW_OOB] = 1; id = 0; }
-        load_row_slice<G, EPL>(emb, id, dp, gl, dst);
+        id = fids[fj];
         const bool c = fj >= fpl && fj < fpl + fk;
         const bool c1 = (fj - 1u) >= fpl && (fj - 1u) < fpl + fk;   // fj - 1 wraps for fj == 0: false
         const bool c2 = (fj - 2u) >= fpl && (fj - 2u) < fpl + fk;
         meta = 8u | (fj == 0u ? 4u : 0u) | ((fj >= 1u && (c || c1)) ? 1u : 0u) | ((fj >= 2u && (c || c2)) ? 2u : 0u);
-        if (++fj == fL) {
-            fo += n_groups;
-            if (fo >= n_occ) f_more = false;
-        }
+        ++fj;
     };
     uint32_t wr = 0;   // write cursor into dots[]
-    // one pipeline step: CUR becomes current (its load was issued two steps ago), NXT receives a new fetch
-#define SAGE_DOT_STEP(CUR, P1, P2, NXT)                                     \
-    {                                                                       \
-        m0 = ma; out0 = outa; ma = mb; outa = outb;                         \
-        fetch(NXT, mb, outb);                                               \
-        if (m0 & 8u) {                                                      \
-            if (m0 & 4u) wr = out0;                                         \
-            if (m0 & 1u) {                                                  \
-                const double d_ = group_dot<G, EPL>(CUR, P1);               \
-                if (gl == 0) dots[wr] = d_;                                 \
-                ++wr;                                                       \
-            }                                                               \
-            if (m0 & 2u) {                                                  \
-                const double d_ = group_dot<G, EPL>(CUR, P2);               \
-                if (gl == 0) dots[wr] = d_;                                 \
-                ++wr;                                                       \
-            }                                                               \
-        }                                                                   \
+#pragma unroll
+    for (int i = 0; i < NI; ++i) fetch_id(qid[i], qm[NF + i], qo[NF + i]);
+    for (;;) {
+        uint32_t pending = 0;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) pending |= qm[i];
+        if (!__any(pending & 8u)) break;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            // slot s becomes current (its load was issued NF steps ago); the slot freed by the last step takes the row
+            // of the oldest id; a new id load joins the queue
+            const uint32_t m0 = qm[0], out0 = qo[0];
+            uint32_t rid = qid[0];
+            const bool rlive = (qm[NF] & 8u) != 0u;
+#pragma unroll
+            for (int i = 0; i + 1 < NQ; ++i) { qm[i] = qm[i + 1]; qo[i] = qo[i + 1]; }
+#pragma unroll
+            for (int i = 0; i + 1 < NI; ++i) qid[i] = qid[i + 1];
+            fetch_id(qid[NI - 1], qm[NQ - 1], qo[NQ - 1]);
+            if (rid >= emb_rows) { if (rlive) flags[FLAG_ROW_OOB] = 1; rid = 0; }
+            load_row_slice<G, EPL>(emb, rid, dp, gl, B[(s + NF) % NS]);
+            if (m0 & 8u) {
+                if (m0 & 4u) wr = out0;
+                if (m0 & 1u) {
+                    const double d_ = group_dot<G, EPL, T>(B[s], B[(s + NS - 1) % NS]);
+                    if (gl == 0) dots[wr] = d_;
+                    ++wr;
+                }
+                if (m0 & 2u) {
+                    const double d_ = group_dot<G, EPL, T>(B[s], B[(s + NS - 2) % NS]);
+                    if (gl == 0) dots[wr] = d_;
+                    ++wr;
+                }
+            }
+        }
     }
-    fetch(B0, ma, outa);
-    fetch(B1, mb, outb);
-    while (__any(ma & 8u)) {
-        SAGE_DOT_STEP(B0, B4, B3, B2)
-        SAGE_DOT_STEP(B1, B0, B4, B3)
-        SAGE_DOT_STEP(B2, B1, B0, B4)
-        SAGE_DOT_STEP(B3, B2, B1, B0)
-        SAGE_DOT_STEP(B4, B3, B2, B1)
-    }
-#undef SAGE_DOT_STEP
 }
 
 // ----------------------------------------------------------------------------------------------------------

@@ -196,11 +196,14 @@ def make_vocab(corpus: np.ndarray, offsets: np.ndarray, vocab_size: int, max_len
     return vocab
 
 
-def make_embeddings(vocab_size: int, dim: int = 50, seed: int = DEFAULT_SEED) -> np.ndarray:
+def make_embeddings(vocab_size: int, dim: int = 50, seed: int = DEFAULT_SEED, unseen: np.ndarray | None = None) -> np.ndarray:
     """[V, D] float64 shaped like `train_embeddings` output (embeddings.py:77-89): float32 word2vec vectors
-    upcast to float64, with 2 % of the rows replaced by the uniform(+-0.5/D) fallback of embeddings.py:86."""
+    upcast to float64 for the tokens the tokenized corpus contains, the float64 uniform(+-0.5/D) draw of
+    embeddings.py:86 for the others.  `unseen` marks the latter rows; by default 2 % of the rows, at random."""
     rs = np.random.RandomState(seed % (2 ** 32))
     emb = rs.normal(0.0, 0.25, size=(vocab_size, dim)).astype(np.float32).astype(np.float64)
     miss = rs.random_sample(vocab_size) < 0.02
+    if unseen is not None:
+        miss = np.asarray(unseen, dtype=bool)
     emb[miss] = rs.uniform(-0.5 / dim, 0.5 / dim, size=(int(miss.sum()), dim))
     return emb

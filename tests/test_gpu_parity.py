@@ -174,6 +174,44 @@ def test_step_vs_oracle(style, max_len, dim):
         eng.close()
 
 
+@pytest.mark.parametrize("kind", ["f32_exact", "mixed", "f64_all"])
+def test_score_storage_modes(kind):
+    """float32 row storage (score mode 0) is lossless: exact rows are gathered from the float32 copy, every pair that
+    touches another row is recomputed from the float64 matrix.  Both modes must agree with the oracle."""
+    from oracle import sage_oracle as orc
+    from sage_amd import synth
+    from sage_amd.parallel import segment_line_bounds
+    corpus, off = synth.make_corpus(300, seed=77, style="en", n_types=2000, mean_log_words=2.8)
+    vocab = synth.make_vocab(corpus, off, 2500, 16, sample_bytes=300_000)
+    rs = np.random.RandomState(3)
+    emb = rs.normal(0.0, 0.3, size=(len(vocab), 50))
+    if kind != "f64_all":
+        emb = emb.astype(np.float32).astype(np.float64)
+    if kind == "mixed":
+        miss = rs.random_sample(len(vocab)) < 0.1
+        emb[miss] = rs.uniform(-0.01, 0.01, size=(int(miss.sum()), 50))
+    lines = synth.corpus_lines(corpus, off)
+    tok = orc.OracleTokenizer(vocab, 16)
+    occs = {}
+    losses, tt, ttr, sizes = orc.run_shard(tok, lines, emb, flush=10_000, occurrences=occs)
+    bounds = segment_line_bounds(len(lines), 1)
+    for mode in (0, 1):
+        eng = _engine()
+        eng.set_score_mode(mode)
+        eng.set_vocab(vocab, None, 16)
+        eng.set_corpus(corpus, off)
+        eng.set_embeddings(emb)
+        _check_step(eng, bounds, tt, ttr, losses, sizes, want_occ=occs)
+        st = eng.step_stats()
+        want_bytes = 4 if (mode == 0 and kind != "f64_all") else 8
+        assert st["emb_elem_bytes"] == want_bytes, st
+        if kind == "mixed" and mode == 0:
+            assert 0 < st["f64_fix_occurrences"] < st["occurrences"], st
+        else:
+            assert st["f64_fix_occurrences"] == 0, st
+        eng.close()
+
+
 def test_long_windows_vs_oracle():
     """Ablations into more pieces than a 64-byte descriptor holds (k up to 20) and never-rejoining ablations take
     the streaming fallback; results must not change."""
