@@ -236,11 +236,18 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, args),
                          "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step,
-                         "algorithmic_bytes_per_launch": per_kernel_bytes[dom] / launches_per_step},
+                         "algorithmic_bytes_per_launch": per_kernel_bytes[dom] / launches_per_step,
+                         "note": ("k_match_lds is bound by integer VALU issue (15 prefix hashes + filter probes per corpus byte), "
+                                  "not by HBM: see DESIGN.md, Kernels") if dom == "match" else ""},
             "step_roofline": {"bytes_per_token_A": A, "achieved_GBs_per_gpu": step_gbs, "frac": step_gbs / HBM_PEAK_GBS,
                               "b_bar": b_bar, "f_m": f_m, "r_bar": r_bar, "p_bar": p_bar, "emb_elem_bytes": eb,
                               "f64_fix_occurrences": st["f64_fix_occurrences"]},
             "kernel_ms_per_step": {k: kt[k][0] / args.steps for k in kt},
+            # every kernel class against the HBM roofline: algorithmic bytes per step / its time per step
+            "kernel_roofline": {k: {"algorithmic_GB_per_step": per_kernel_bytes[k] / 1e9,
+                                    "GBps": per_kernel_bytes[k] / (kt[k][0] / args.steps * 1e-3) / 1e9 if kt[k][0] > 0 else 0.0,
+                                    "frac": per_kernel_bytes[k] / (kt[k][0] / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS if kt[k][0] > 0 else 0.0}
+                                for k in per_kernel_bytes},
             "setup_s": {"generate": gen_s, "upload": upload_s},
         }
         if args.cpu_lines >= 0 and world == 1:
