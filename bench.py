@@ -42,6 +42,8 @@ def pmc_traffic(kernel_class, args):
     if not files:
         return None
     want = CLASS_KERNEL.get(kernel_class)
+    if kernel_class == "__step_total__":
+        want = "__step_total__"
     for row in json.loads(files[-1].read_text()):
         if want and row["kernel"].startswith(want):
             return (row["fetch_x2_GB_per_launch"] + row["write_GB_per_launch"]) * 1e9
@@ -239,7 +241,8 @@ def main():
                          "algorithmic_bytes_per_launch": per_kernel_bytes[dom] / launches_per_step,
                          "note": ("k_match_lds is bound by integer VALU issue (15 prefix hashes + filter probes per corpus byte), "
                                   "not by HBM: see DESIGN.md, Kernels") if dom == "match" else ""},
-            "step_roofline": {"bytes_per_token_A": A, "achieved_GBs_per_gpu": step_gbs, "frac": step_gbs / HBM_PEAK_GBS,
+            "step_roofline": {"measured_hbm_bytes_per_step": pmc_traffic("__step_total__", args) if world == 1 else None,
+                              "bytes_per_token_A": A, "achieved_GBs_per_gpu": step_gbs, "frac": step_gbs / HBM_PEAK_GBS,
                               "b_bar": b_bar, "f_m": f_m, "r_bar": r_bar, "p_bar": p_bar, "emb_elem_bytes": eb,
                               "f64_fix_occurrences": st["f64_fix_occurrences"]},
             "kernel_ms_per_step": {k: kt[k][0] / args.steps for k in kt},

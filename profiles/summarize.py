@@ -31,7 +31,22 @@ for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["FETCH_SIZE"]):
     rows.append({"kernel": k, "launches": a["launches"], "fetch_GB_per_launch": a["FETCH_SIZE"] * 1024 / n / 1e9,
                  "fetch_x2_GB_per_launch": 2 * a["FETCH_SIZE"] * 1024 / n / 1e9,
                  "write_GB_per_launch": a["WRITE_SIZE"] * 1024 / n / 1e9})
+# Whole-step HBM-side bytes: per-launch bytes x launches per timed step.  The kernel-trace run holds 4 steps (1 warm-up
+# + 3 timed) plus the set-up tokenization, the PMC runs hold 1 step plus the same set-up, so the difference / 3 is the
+# number of launches one step makes.
+kt_calls = {}
+for r in csv.DictReader(open(src / "kt/run_kernel_stats.csv")):
+    kt_calls[r["Name"].split("(")[0].replace("void ", "")] = int(r["Calls"])
+step_fetch = step_write = 0.0
+for r in rows:
+    per_step = max(0.0, (kt_calls.get(r["kernel"], 0) - r["launches"]) / 3.0)
+    r["launches_per_step"] = per_step
+    step_fetch += r["fetch_x2_GB_per_launch"] * per_step
+    step_write += r["write_GB_per_launch"] * per_step
+rows.append({"kernel": "__step_total__", "launches": 0, "fetch_GB_per_launch": step_fetch / 2, "fetch_x2_GB_per_launch": step_fetch,
+             "write_GB_per_launch": step_write, "launches_per_step": 1.0})
 json.dump(rows, open(dst / f"{tag}_pmc_traffic.json", "w"), indent=1)
+print(f"step total: fetch x2 {step_fetch:.1f} GB + write {step_write:.1f} GB")
 for r in rows[:12]:
     print(f"{r['kernel']:28s} n={r['launches']:3d} fetch={r['fetch_GB_per_launch']:8.2f} GB (x2 {r['fetch_x2_GB_per_launch']:8.2f})"
           f" write={r['write_GB_per_launch']:7.2f} GB")
