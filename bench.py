@@ -98,11 +98,28 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
+    # SAGE_BENCH_REHEARSE=1: run the N>1 code path on a ONE-GPU box (every rank on cuda:0, gloo, collectives staged
+    # through host memory).  For checking the multi-rank flow only; its numbers mean nothing.
+    rehearse = os.environ.get("SAGE_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def all_reduce_(t, op=None):
+        op = op or dist.ReduceOp.SUM
+        if rehearse:
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op)
 
     from sage_amd import synth
     from sage_amd._lib import HipSage
@@ -141,7 +158,7 @@ def main():
     seen_counts = np.bincount(eng.tokenize(0, len(offsets) - 1)[0], minlength=len(vocab)).astype(np.int64)
     if world > 1:
         t = torch.from_numpy(seen_counts).cuda()
-        dist.all_reduce(t)
+        all_reduce_(t)
         seen_counts = t.cpu().numpy()
     seen = seen_counts > 0
     emb = synth.make_embeddings(len(vocab), args.dim, seed=seed, unseen=~seen)
@@ -159,7 +176,12 @@ def main():
 
     def step():
         eng.ablation_step_device(bounds, (d_loss.data_ptr(), V), d_occ.data_ptr(), d_tot.data_ptr(), (d_hist.data_ptr(), H))
-        if world > 1:
+        if world > 1 and rehearse:
+            from sage_amd.dist import combine_host
+            l, o, h, t = combine_host(dist, d_loss.cpu().numpy(), d_occ.cpu().numpy(), d_hist.cpu().numpy(), d_tot.cpu().numpy())
+            d_loss.copy_(torch.from_numpy(l)); d_occ.copy_(torch.from_numpy(o))
+            d_hist.copy_(torch.from_numpy(h)); d_tot.copy_(torch.from_numpy(t))
+        elif world > 1:
             from sage_amd.dist import combine_device
             combine_device(dist, d_loss, d_occ, d_hist, d_tot)
 
@@ -183,7 +205,7 @@ def main():
     log(f"{args.steps} timed steps: {dt:.3f} s")
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        all_reduce_(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     total_tokens = int(d_tot[0].item())      # whole job (already combined over ranks)
     total_triples = int(d_tot[1].item())

@@ -128,8 +128,8 @@ int sage_set_count_mode(sage_ctx* ctx, int mode);
  * both modes).  0 (default): rows whose values are all float32-representable -- every row train_embeddings fills
  * from word2vec (embeddings.py:81) -- are gathered from a float32 copy (half the bytes; products of two float32
  * are exact in float64), and every pair that touches another row (the float64 uniform rows of embeddings.py:86) is
- * recomputed from the float64 matrix; if more than a quarter of the rows are not float32-representable the float64
- * matrix is used for everything.  1: float64 storage only.  Takes effect at the next sage_set_embeddings. */
+ * recomputed from the float64 matrix; if more than half of the rows are not float32-representable, or a step finds
+ * that more than 30 % of the occurrences touch such a row, the float64 matrix is used for everything.  1: float64 storage only.  Takes effect at the next sage_set_embeddings. */
 int sage_set_score_mode(sage_ctx* ctx, int mode);
 
 /* Workload statistics of the last step, for the roofline's algorithmic bytes:

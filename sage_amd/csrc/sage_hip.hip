@@ -284,7 +284,7 @@ void launch_score(sage_ctx* c, const uint32_t* tok_w0, uint32_t n_tok, uint32_t 
     }
     {
         Prof p(c, SAGE_K_LOGSIG);
-        const uint32_t grid = std::min<uint32_t>(cdiv(n_occ, 32), 256u * 8u);
+        const uint32_t grid = std::min<uint32_t>(cdiv(n_occ, LOGSIG_TILE), 256u * 8u);
         k_logsig<<<grid, 256, 0, c->stream>>>(c->desc.as<uint4>(), c->occ_tok.as<uint32_t>(), tok_w0, n_occ,
                                               c->dot_off.as<uint32_t>(), c->dots.as<double>(), c->gcache.as<double2>(),
                                               c->loss.as<double>());
@@ -490,6 +490,10 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
         c->step_stats[5] = (int64_t)stats[STAT_PAIRS];
         c->step_stats[6] = c->use_f32 ? 4 : 8;   // bytes per stored embedding element on the main scoring pass
         c->step_stats[7] = (int64_t)stats[STAT_INEXACT];
+        // The share of ROWS that float32 cannot hold says little about the share of OCCURRENCES that touch one; the
+        // step just measured the latter.  Above 30 % the float64 pass costs more than the float32 copy saves: later
+        // steps (until the next sage_set_embeddings) use the float64 matrix alone.  Results do not depend on this.
+        if (c->use_f32 && c->score_mode == 0 && (double)stats[STAT_INEXACT] > 0.30 * (double)total_occ) c->use_f32 = false;
         return SAGE_OK;
     }
 }
@@ -667,7 +671,7 @@ int sage_set_embeddings(sage_ctx* c, const double* emb, int64_t rows, int32_t di
         if (!exact) { bitmap[(size_t)r >> 5] |= 1u << (r & 31); ++n_inexact; }
     }
     c->n_inexact = n_inexact;
-    c->use_f32 = (c->score_mode == 0 && n_inexact * 4 <= rows) || (c->score_mode == 2 && n_inexact < rows);
+    c->use_f32 = (c->score_mode == 0 && n_inexact * 2 <= rows) || (c->score_mode == 2 && n_inexact < rows);
     if (c->use_f32) {
         if ((rc = ensure(c, c->emb32, e32.size() * 4))) return rc;
         if ((rc = ensure(c, c->inexact, bitmap.size() * 4))) return rc;

@@ -426,32 +426,62 @@ __global__ __launch_bounds__(256) void k_dots(const uint4* __restrict__ desc, co
 
 // ----------------------------------------------------------------------------------------------------------
 // k_logsig: loss[a] += -2 * ( sum_{ablated pairs} logsig(dot)  -  sum_{base pairs} G )   (utils.py:125-138,255; every
-// position pair stands for both (t,c) orders).  8 lanes per occurrence stride over its dots; the base window is a
-// range sum over the pair cache.
+// position pair stands for both (t,c) orders).  Window lengths are heavy-tailed, so the dots are NOT walked per
+// occurrence: a workgroup takes 256 consecutive occurrences, cuts their contiguous run of dots into 256 equal slices
+// (one per thread, whatever occurrence they belong to), and every thread adds its partial sums into per-occurrence
+// LDS accumulators, following the occurrence boundaries as it goes.  A second phase (one thread per occurrence) adds
+// the base window as a range sum over the pair cache and accumulates per ablated id.
 // ----------------------------------------------------------------------------------------------------------
+#define LOGSIG_TILE 256
 __global__ __launch_bounds__(256) void k_logsig(const uint4* __restrict__ desc, const uint32_t* __restrict__ occ_tok,
                                                 const uint32_t* __restrict__ tok_w0, uint32_t n_occ,
                                                 const uint32_t* __restrict__ dot_off, const double* __restrict__ dots,
                                                 const double2* __restrict__ Gc, double* __restrict__ loss) {
-    constexpr int G = 8;
     __shared__ uint32_t acc_id[ACC_SLOTS];
     __shared__ double acc_val[ACC_SLOTS];
+    __shared__ uint32_t off[LOGSIG_TILE + 1];
+    __shared__ double osum[LOGSIG_TILE];
     for (uint32_t i = threadIdx.x; i < ACC_SLOTS; i += 256) { acc_id[i] = ACC_EMPTY; acc_val[i] = 0.0; }
-    __syncthreads();
-    const uint32_t gl = threadIdx.x % G;
     const double* Gd = reinterpret_cast<const double*>(Gc);
-    const uint32_t n_round = (n_occ + 31u) & ~31u;
-    for (uint32_t o0 = blockIdx.x * 32u; o0 < n_round; o0 += gridDim.x * 32u) {
-        const uint32_t o = o0 + threadIdx.x / G;
-        double acc = 0.0;
-        uint32_t a = 0;
-        if (o < n_occ) {
-            const uint4 h = desc[(size_t)o * 4];
+    for (uint32_t o0 = blockIdx.x * LOGSIG_TILE; o0 < n_occ; o0 += gridDim.x * LOGSIG_TILE) {
+        const uint32_t nt = min((uint32_t)LOGSIG_TILE, n_occ - o0);   // occurrences of this tile
+        __syncthreads();
+        if (threadIdx.x < nt) off[threadIdx.x] = dot_off[o0 + threadIdx.x];
+        if (threadIdx.x == 0) off[nt] = dot_off[o0 + nt];   // nt can be 256: there is no thread 256
+        osum[threadIdx.x] = 0.0;
+        // phase-2 operands are independent of phase 1: issue their loads first
+        const uint32_t o = o0 + threadIdx.x;
+        uint4 h = make_uint4(0, 0, 0, 0);
+        uint32_t t = 0;
+        if (threadIdx.x < nt) { h = desc[(size_t)o * 4]; t = occ_tok[o]; }
+        __syncthreads();
+        const uint32_t d0 = off[0], d1 = off[nt];
+        const uint32_t per = (d1 - d0 + 255u) / 256u;
+        uint32_t i = d0 + threadIdx.x * per;
+        const uint32_t iend = min(d1, i + per);
+        if (i < iend) {
+            // owner of dot i: largest j with off[j] <= i
+            uint32_t lo = 0, hi = nt;
+            while (hi - lo > 1u) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (off[mid] <= i) lo = mid; else hi = mid;
+            }
+            uint32_t own = lo, nxt = off[own + 1];
+            double acc = 0.0;
+            for (; i < iend; ++i) {
+                if (i >= nxt) {
+                    unsafeAtomicAdd(&osum[own], acc);
+                    acc = 0.0;
+                    do { ++own; nxt = off[own + 1]; } while (i >= nxt);
+                }
+                acc += log_sigmoid(dots[i]);
+            }
+            unsafeAtomicAdd(&osum[own], acc);
+        }
+        __syncthreads();
+        if (threadIdx.x < nt) {
             const Win w = win_decode(h.x, h.z, h.w);
-            const uint32_t t = occ_tok[o];
-            a = SAGE_T_ID(tok_w0[t]);
-            const uint32_t d0 = dot_off[o], d1 = dot_off[o + 1];
-            for (uint32_t i = d0 + gl; i < d1; i += G) acc += log_sigmoid(dots[i]);
+            const uint32_t a = SAGE_T_ID(tok_w0[t]);
             // base window: pair (i,i+1) counts iff i or i+1 is in the centre [t, t+m): rel = i-t in [-1, m-1] clipped to
             // the window [t-pl, t+m+pr-1]; pair (i,i+2) iff rel in [0,m-1] or rel+2 in [0,m-1] (not contiguous for
             // m == 1: rel = -1 joins two pads).
@@ -459,14 +489,11 @@ __global__ __launch_bounds__(256) void k_logsig(const uint4* __restrict__ desc, 
             const int lo1 = ipl >= 1 ? -1 : 0, hi1 = im - 2 + (ipr >= 1 ? 1 : 0);
             const int lo2 = -ipl, hi2 = im + ipr - 3;
             double sb = 0.0;
-            for (int rel = lo1 + (int)gl; rel <= hi1; rel += G) sb += Gd[((size_t)t + rel) * 2];
-            for (int rel = lo2 + (int)gl; rel <= hi2; rel += G)
+            for (int rel = lo1; rel <= hi1; ++rel) sb += Gd[((size_t)t + rel) * 2];
+            for (int rel = lo2; rel <= hi2; ++rel)
                 if ((rel >= 0 && rel <= im - 1) || (rel + 2 >= 0 && rel + 2 <= im - 1)) sb += Gd[((size_t)t + rel) * 2 + 1];
-            acc -= sb;
+            acc_add_f64(acc_id, acc_val, loss, a, -2.0 * (osum[threadIdx.x] - sb));
         }
-#pragma unroll
-        for (int mm = G / 2; mm >= 1; mm >>= 1) acc += __shfl_xor(acc, mm, G);
-        if (gl == 0 && o < n_occ) acc_add_f64(acc_id, acc_val, loss, a, -2.0 * acc);
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < ACC_SLOTS; i += 256)

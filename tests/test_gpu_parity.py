@@ -195,7 +195,9 @@ def test_score_storage_modes(kind):
     occs = {}
     losses, tt, ttr, sizes = orc.run_shard(tok, lines, emb, flush=10_000, occurrences=occs)
     bounds = segment_line_bounds(len(lines), 1)
-    for mode in (0, 1):
+    # mode 0 = automatic (may fall back to float64 when many occurrences touch an inexact row), 1 = float64 only,
+    # 2 = float32 copy whenever at least one row is exact
+    for mode in (0, 1, 2):
         eng = _engine()
         eng.set_score_mode(mode)
         eng.set_vocab(vocab, None, 16)
@@ -203,12 +205,14 @@ def test_score_storage_modes(kind):
         eng.set_embeddings(emb)
         _check_step(eng, bounds, tt, ttr, losses, sizes, want_occ=occs)
         st = eng.step_stats()
-        want_bytes = 4 if (mode == 0 and kind != "f64_all") else 8
-        assert st["emb_elem_bytes"] == want_bytes, st
-        if kind == "mixed" and mode == 0:
-            assert 0 < st["f64_fix_occurrences"] < st["occurrences"], st
-        else:
-            assert st["f64_fix_occurrences"] == 0, st
+        if mode == 1 or kind == "f64_all":
+            assert st["emb_elem_bytes"] == 8 and st["f64_fix_occurrences"] == 0, st
+        elif mode == 2 or kind == "f32_exact":
+            assert st["emb_elem_bytes"] == 4, st
+            if kind == "mixed":
+                assert 0 < st["f64_fix_occurrences"] < st["occurrences"], st
+            else:
+                assert st["f64_fix_occurrences"] == 0, st
         eng.close()
 
 
