@@ -44,10 +44,11 @@ SAGE_HD uint64_t sage_mix64(uint64_t k) {
     return k;
 }
 
-// A match-table entry per corpus byte: x = id1 | len1<<20 (longest key at this byte, never crossing the line
-// end), y = id2 | len2<<20 (second longest; len2 == 0 iff len1 == 1).
+// A match-table entry per corpus byte: x = id1 | len1<<20 | ends<<31 (longest key at this byte, never crossing the
+// line end; ends = it reaches the line end exactly), y = id2 | len2<<20 (second longest; len2 == 0 iff len1 == 1).
 #define SAGE_M_ID(w) ((w) & SAGE_ID_MASK)
-#define SAGE_M_LEN(w) ((w) >> 20)
+#define SAGE_M_LEN(w) (((w) >> 20) & 0x3Fu)
+#define SAGE_M_ENDS(w) ((w) >> 31)
 
 // Token word: id | min(index in line, 3) << 20 | min(tokens after it in the line, 3) << 22
 #define SAGE_T_ID(w) ((w) & SAGE_ID_MASK)
@@ -61,7 +62,6 @@ SAGE_HD uint64_t sage_mix64(uint64_t k) {
 #define SAGE_DH_VALID 0x80000000u
 #define SAGE_DH_OVER 0x40000000u
 #define SAGE_DH_NEVER 0x20000000u
-#define SAGE_DH_INEXACT 0x10000000u  // the ablated window holds a row whose values are not float32-representable
 #define SAGE_DH_K(h) ((h) & 0xFFFu)
 #define SAGE_DH_M(h) (((h) >> 12) & 0xFFFu)
 #define SAGE_DH_PL(h) (((h) >> 24) & 3u)

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -44,6 +45,7 @@ struct sage_ctx {
     // corpus
     DevBuf corpus, rem, line_off;
     std::vector<int64_t> h_line_off;
+    int64_t max_line_bytes = 0;
     int64_t n_lines = 0, nbytes = 0;
     bool have_corpus = false;
 
@@ -52,6 +54,7 @@ struct sage_ctx {
     DevBuf emb32;         // float32 rows, when most rows are float32-representable (word2vec output is)
     DevBuf inexact;       // bitmap of the rows that are not: their pairs are recomputed from `emb`
     DevBuf inex_list, inex_count;
+    DevBuf long_list, long_count;   // occurrences whose window does not fit the inline descriptor (k_describe<true>)
     int64_t emb_rows = 0, n_inexact = 0;
     int dim = 0, dp = 0;
     bool have_emb = false;
@@ -59,7 +62,7 @@ struct sage_ctx {
     int score_mode = 0;   // 0 = float32 storage when lossless for most rows, 1 = always float64 storage
 
     // scratch (grow-only; nothing is allocated in the steady state)
-    DevBuf M, ntok, tokoff, tile_sums, grand_total, tok_w0, tok_pos, set, seg_line_rel, seg_tok_off, set_base, set_mask, seg_pairs, desc, gcache, hist1, bucket_off, rec_a, rec_b,
+    DevBuf M, ntok, tokoff, tile_sums, grand_total, tok_w0, occ_pos, set, seg_line_rel, seg_tok_off, set_base, set_mask, seg_pairs, desc, gcache, hist1, bucket_off, rec_a, rec_b,
         nocc, occoff, occ_tok, np_ab, dot_off, dots, pool, pool_cursor;
     int pool_factor = 8;  // id-pool words per occurrence (grown on overflow)
     int count_mode = 0;  // 0 = partition + LDS dedupe (v2), 1 = per-segment HBM sets (v1, also the overflow fallback)
@@ -232,62 +235,81 @@ int padded_dim(int dim) {
     return 0;
 }
 
-template <int G, int EPL, int GD, int EPLD, typename T>
-void launch_pairs_dots(sage_ctx* c, const T* emb, const uint32_t* tok_w0, uint32_t n_tok, uint32_t n_occ, bool fix) {
-    // G x EPL = lanes per row x elements per lane of the pair cache, GD x EPLD of the window dots
-    const uint32_t* bitmap = c->inexact.as<uint32_t>();
-    {
-        Prof p(c, SAGE_K_PAIRS);
-        const uint32_t grid = std::min<uint32_t>(cdiv(cdiv(n_tok, 4), 256 / G), 256u * 16u);
-        if (fix)
-            k_pair_cache<G, EPL, T, true><<<grid, 256, 0, c->stream>>>(tok_w0, n_tok, emb, (uint32_t)c->emb_rows, (uint32_t)c->dp,
-                                                                       c->gcache.as<double2>(), c->flags.as<uint32_t>(), bitmap);
-        else
-            k_pair_cache<G, EPL, T, false><<<grid, 256, 0, c->stream>>>(tok_w0, n_tok, emb, (uint32_t)c->emb_rows, (uint32_t)c->dp,
-                                                                        c->gcache.as<double2>(), c->flags.as<uint32_t>(), nullptr);
-    }
-    {
-        Prof p(c, SAGE_K_SCORE);
-        const uint32_t grid = std::min<uint32_t>(cdiv(n_occ, 256 / GD), (uint32_t)c->n_cu * (sizeof(T) == 4 ? 5u : 4u));
-        k_dots<GD, EPLD, T, 5><<<grid, 256, 0, c->stream>>>(
-            c->desc.as<uint4>(), c->pool.as<uint32_t>(), n_occ, c->dot_off.as<uint32_t>(), emb, (uint32_t)c->emb_rows,
-            (uint32_t)c->dp, c->dots.as<double>(), c->flags.as<uint32_t>(),
-            fix ? c->inex_list.as<uint32_t>() : nullptr, fix ? c->inex_count.as<uint32_t>() : nullptr);
-    }
+// G x EPL = lanes per row x elements per lane
+template <int G, int EPL, typename T>
+void launch_pairs(sage_ctx* c, const T* emb, const uint32_t* tok_w0, uint32_t n_tok, bool fix) {
+    Prof p(c, SAGE_K_PAIRS);
+    const uint32_t grid = std::min<uint32_t>(cdiv(cdiv(n_tok, 4), 256 / G), 256u * 16u);
+    if (fix)
+        k_pair_cache<G, EPL, T, true><<<grid, 256, 0, c->stream>>>(tok_w0, n_tok, emb, (uint32_t)c->emb_rows, (uint32_t)c->dp,
+                                                                   c->gcache.as<double2>(), c->flags.as<uint32_t>(),
+                                                                   c->inexact.as<uint32_t>());
+    else
+        k_pair_cache<G, EPL, T, false><<<grid, 256, 0, c->stream>>>(tok_w0, n_tok, emb, (uint32_t)c->emb_rows, (uint32_t)c->dp,
+                                                                    c->gcache.as<double2>(), c->flags.as<uint32_t>(), nullptr);
 }
 
-// pair cache + window dots (float32 rows first and a float64 pass over the flagged occurrences, or float64 only),
-// then the log-sigmoid reduction
+template <int G, int EPL, typename T>
+void launch_dots(sage_ctx* c, const T* emb, uint32_t n_occ, bool listed) {
+    Prof p(c, SAGE_K_SCORE);
+    const uint32_t grid = std::min<uint32_t>(cdiv(n_occ, 256 / G), (uint32_t)c->n_cu * (sizeof(T) == 4 ? 5u : 4u));
+    k_dots<G, EPL, T, 5><<<grid, 256, 0, c->stream>>>(
+        c->desc.as<uint4>(), c->pool.as<uint32_t>(), n_occ, c->dot_off.as<uint32_t>(), emb, (uint32_t)c->emb_rows,
+        (uint32_t)c->dp, c->dots.as<double>(), c->flags.as<uint32_t>(),
+        listed ? c->inex_list.as<uint32_t>() : nullptr, listed ? c->inex_count.as<uint32_t>() : nullptr);
+}
+
+// instantiation per padded row width: float32 rows are whole 16-byte loads of 4 elements, float64 rows of 2
+#define SAGE_BY_WIDTH_F32(FN, ...)                       \
+    switch (c->dp) {                                     \
+    case 32: FN<8, 4>(__VA_ARGS__); break;               \
+    case 64: FN<8, 8>(__VA_ARGS__); break;               \
+    case 128: FN<16, 8>(__VA_ARGS__); break;             \
+    case 256: FN<32, 8>(__VA_ARGS__); break;             \
+    case 384: FN<32, 12>(__VA_ARGS__); break;            \
+    default: FN<64, 8>(__VA_ARGS__); break;              \
+    }
+#define SAGE_BY_WIDTH_F64(FN, ...)                       \
+    switch (c->dp) {                                     \
+    case 32: FN<8, 4>(__VA_ARGS__); break;               \
+    case 64: FN<8, 8>(__VA_ARGS__); break;               \
+    case 128: FN<16, 8>(__VA_ARGS__); break;             \
+    case 256: FN<32, 8>(__VA_ARGS__); break;             \
+    case 384: FN<64, 6>(__VA_ARGS__); break;             \
+    default: FN<64, 8>(__VA_ARGS__); break;              \
+    }
+
+// Scoring of one batch.  float32 row storage: pair cache and window dots from the float32 copy (rows it cannot hold
+// are NaN there); token quads that touch such a row are recomputed from the float64 matrix (bitmap test); k_logsig
+// lists the occurrences whose sum came out NaN, and their dots and sums are redone from the float64 matrix.
 void launch_score(sage_ctx* c, const uint32_t* tok_w0, uint32_t n_tok, uint32_t n_occ) {
     const double* e64 = c->emb.as<double>();
     const float* e32 = c->emb32.as<float>();
     const bool fix = c->use_f32 && c->n_inexact > 0;
     if (c->use_f32) {
-        switch (c->dp) {
-        case 32: launch_pairs_dots<8, 4, 8, 4>(c, e32, tok_w0, n_tok, n_occ, false); break;
-        case 64: launch_pairs_dots<8, 8, 8, 8>(c, e32, tok_w0, n_tok, n_occ, false); break;
-        case 128: launch_pairs_dots<16, 8, 16, 8>(c, e32, tok_w0, n_tok, n_occ, false); break;
-        case 256: launch_pairs_dots<32, 8, 32, 8>(c, e32, tok_w0, n_tok, n_occ, false); break;
-        case 384: launch_pairs_dots<32, 12, 32, 12>(c, e32, tok_w0, n_tok, n_occ, false); break;
-        default: launch_pairs_dots<64, 8, 64, 8>(c, e32, tok_w0, n_tok, n_occ, false); break;
-        }
-    }
-    if (!c->use_f32 || fix) {
-        switch (c->dp) {
-        case 32: launch_pairs_dots<8, 4, 8, 4>(c, e64, tok_w0, n_tok, n_occ, fix); break;
-        case 64: launch_pairs_dots<8, 8, 8, 8>(c, e64, tok_w0, n_tok, n_occ, fix); break;
-        case 128: launch_pairs_dots<16, 8, 16, 8>(c, e64, tok_w0, n_tok, n_occ, fix); break;
-        case 256: launch_pairs_dots<32, 8, 32, 8>(c, e64, tok_w0, n_tok, n_occ, fix); break;
-        case 384: launch_pairs_dots<64, 6, 64, 6>(c, e64, tok_w0, n_tok, n_occ, fix); break;
-        default: launch_pairs_dots<64, 8, 64, 8>(c, e64, tok_w0, n_tok, n_occ, fix); break;
-        }
+        SAGE_BY_WIDTH_F32(launch_pairs, c, e32, tok_w0, n_tok, false)
+        if (fix) { SAGE_BY_WIDTH_F64(launch_pairs, c, e64, tok_w0, n_tok, true) }
+        SAGE_BY_WIDTH_F32(launch_dots, c, e32, n_occ, false)
+    } else {
+        SAGE_BY_WIDTH_F64(launch_pairs, c, e64, tok_w0, n_tok, false)
+        SAGE_BY_WIDTH_F64(launch_dots, c, e64, n_occ, false)
     }
     {
         Prof p(c, SAGE_K_LOGSIG);
         const uint32_t grid = std::min<uint32_t>(cdiv(n_occ, LOGSIG_TILE), 256u * 8u);
         k_logsig<<<grid, 256, 0, c->stream>>>(c->desc.as<uint4>(), c->occ_tok.as<uint32_t>(), tok_w0, n_occ,
                                               c->dot_off.as<uint32_t>(), c->dots.as<double>(), c->gcache.as<double2>(),
-                                              c->loss.as<double>());
+                                              c->loss.as<double>(), fix ? c->inex_list.as<uint32_t>() : nullptr,
+                                              c->inex_count.as<uint32_t>());
+    }
+    if (fix) {
+        SAGE_BY_WIDTH_F64(launch_dots, c, e64, n_occ, true)
+        Prof p(c, SAGE_K_LOGSIG);
+        const uint32_t grid = std::min<uint32_t>(cdiv(n_occ, 32), 256u * 8u);
+        k_logsig_list<<<grid, 256, 0, c->stream>>>(c->desc.as<uint4>(), c->occ_tok.as<uint32_t>(), tok_w0,
+                                                   c->inex_list.as<uint32_t>(), c->inex_count.as<uint32_t>(),
+                                                   c->dot_off.as<uint32_t>(), c->dots.as<double>(), c->gcache.as<double2>(),
+                                                   c->loss.as<double>(), c->stats.as<unsigned long long>());
     }
 }
 
@@ -349,17 +371,17 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
             if (n_tok == 0) { sa = sb; continue; }
 
             if ((rc = ensure(c, c->tok_w0, (size_t)n_tok * 4))) return rc;
-            if ((rc = ensure(c, c->tok_pos, (size_t)n_tok * 4))) return rc;
+            if ((rc = ensure(c, c->occ_pos, (size_t)std::max(n_occ, 1u) * 4))) return rc;
             if ((rc = ensure(c, c->occ_tok, (size_t)std::max(n_occ, 1u) * 4))) return rc;
             {
                 Prof p(c, SAGE_K_WALK);
                 k_walk_write<false><<<cdiv(nl, 256), 256, 0, c->stream>>>(
                     c->line_off.as<int64_t>(), line0, nl, pos0, c->M.as<uint2>(), c->tokoff.as<uint32_t>(),
-                    c->occoff.as<uint32_t>(), c->tok_w0.as<uint32_t>(), c->tok_pos.as<uint32_t>(),
+                    c->occoff.as<uint32_t>(), c->tok_w0.as<uint32_t>(), c->occ_pos.as<uint32_t>(),
                     c->occ_tok.as<uint32_t>(), nullptr, nullptr, nullptr);
             }
             if (n_occ == 0) { HIP_TRY(c, hipGetLastError()); sa = sb; continue; }
-            WalkArrays A{c->M.as<uint2>(), c->rem.as<uint8_t>() + pos0, c->tok_w0.as<uint32_t>(), c->tok_pos.as<uint32_t>()};
+            WalkArrays A{c->M.as<uint2>(), (uint32_t)(c->h_line_off[line1] - pos0), c->tok_w0.as<uint32_t>(), c->occ_pos.as<uint32_t>()};
             if ((rc = ensure(c, c->set_base, (size_t)nsb * 8))) return rc;
             if ((rc = ensure(c, c->set_mask, (size_t)nsb * 8))) return rc;
             if ((rc = ensure(c, c->seg_pairs, (size_t)nsb * 8))) return rc;
@@ -367,7 +389,10 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
             if ((rc = ensure(c, c->gcache, (size_t)n_tok * 16))) return rc;
             if ((rc = ensure(c, c->np_ab, (size_t)n_occ * 4))) return rc;
             if ((rc = ensure(c, c->dot_off, ((size_t)n_occ + 1) * 4))) return rc;
-            const uint64_t pool_cap = std::min<uint64_t>((uint64_t)n_occ * c->pool_factor + 1024, 0xFFFFFF00ull);
+            // never smaller than the longest possible window (<= pads + one id per byte of a line), so that a window
+            // that lost the race for pool space can still be given in-bounds (meaningless) ids: see k_describe<true>
+            const uint64_t pool_cap = std::min<uint64_t>(std::max<uint64_t>((uint64_t)n_occ * c->pool_factor + 1024,
+                                                                            (uint64_t)c->max_line_bytes + 16), 0xFFFFFF00ull);
             if ((rc = ensure(c, c->pool, pool_cap * 4))) return rc;
             HIP_TRY(c, hipMemsetAsync(c->seg_pairs.p, 0, (size_t)nsb * 8, c->stream));
             HIP_TRY(c, hipMemsetAsync(c->pool_cursor.p, 0, 4, c->stream));
@@ -379,15 +404,24 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
             }
             SegPlan S{c->seg_tok_off.as<uint32_t>(), c->set_base.as<uint64_t>(), c->set_mask.as<uint64_t>(), nsb};
             const uint32_t cgrid = std::min<uint32_t>(cdiv(n_occ, 256), 256u * 16u);
+            const uint32_t lgrid = std::min<uint32_t>(cdiv(n_occ, 256), 256u * 8u);   // long-list kernels (grid-stride)
+            if ((rc = ensure(c, c->long_list, (size_t)n_occ * 4))) return rc;
+            if ((rc = ensure(c, c->long_count, 4))) return rc;
+            HIP_TRY(c, hipMemsetAsync(c->long_count.p, 0, 4, c->stream));
             {
                 Prof p(c, SAGE_K_DESCRIBE);
-                k_describe<<<cgrid, 256, 0, c->stream>>>(
+                k_describe<false><<<cgrid, 256, 0, c->stream>>>(
                     A, c->occ_tok.as<uint32_t>(), n_occ, S, c->desc.as<uint4>(), c->np_ab.as<uint32_t>(),
                     c->pool.as<uint32_t>(), c->pool_cursor.as<uint32_t>(), (uint32_t)pool_cap,
                     c->seg_pairs.as<unsigned long long>(), c->occ.as<unsigned long long>(),
                     c->hist.as<unsigned long long>(), (uint32_t)hist_len, c->stats.as<unsigned long long>(),
-                    c->flags.as<uint32_t>(), fix_pass ? c->inexact.as<uint32_t>() : nullptr,
-                    c->inex_list.as<uint32_t>(), c->inex_count.as<uint32_t>());
+                    c->flags.as<uint32_t>(), c->long_list.as<uint32_t>(), c->long_count.as<uint32_t>());
+                k_describe<true><<<lgrid, 256, 0, c->stream>>>(
+                    A, c->occ_tok.as<uint32_t>(), n_occ, S, c->desc.as<uint4>(), c->np_ab.as<uint32_t>(),
+                    c->pool.as<uint32_t>(), c->pool_cursor.as<uint32_t>(), (uint32_t)pool_cap,
+                    c->seg_pairs.as<unsigned long long>(), c->occ.as<unsigned long long>(),
+                    c->hist.as<unsigned long long>(), (uint32_t)hist_len, c->stats.as<unsigned long long>(),
+                    c->flags.as<uint32_t>(), c->long_list.as<uint32_t>(), c->long_count.as<uint32_t>());
             }
             // offsets of every occurrence's ablated-window dots; grand_total[1] is reused for the dot total
             if ((rc = scan_u32(c, c->np_ab.as<uint32_t>(), n_occ, c->dot_off.as<uint32_t>(), c->grand_total.as<uint64_t>() + 1))) return rc;
@@ -404,6 +438,9 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
                     k_key_partition<0><<<cgrid, 256, 0, c->stream>>>(c->desc.as<uint4>(), c->pool.as<uint32_t>(),
                                                                      c->occ_tok.as<uint32_t>(), A.tok_w0, n_occ, S,
                                                                      c->hist1.as<unsigned long long>(), nullptr);
+                    k_key_partition_long<0><<<lgrid, 256, 0, c->stream>>>(
+                        c->desc.as<uint4>(), c->pool.as<uint32_t>(), c->occ_tok.as<uint32_t>(), A.tok_w0,
+                        c->long_list.as<uint32_t>(), c->long_count.as<uint32_t>(), S, c->hist1.as<unsigned long long>(), nullptr);
                 }
                 std::vector<uint64_t> h1(nbk), boff(nbk + 1);
                 HIP_TRY(c, hipMemcpyAsync(h1.data(), c->hist1.p, nbk * 8, hipMemcpyDeviceToHost, c->stream));
@@ -422,6 +459,10 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
                                                                      c->occ_tok.as<uint32_t>(), A.tok_w0, n_occ, S,
                                                                      c->hist1.as<unsigned long long>(),
                                                                      c->rec_a.as<unsigned long long>());
+                    k_key_partition_long<1><<<lgrid, 256, 0, c->stream>>>(
+                        c->desc.as<uint4>(), c->pool.as<uint32_t>(), c->occ_tok.as<uint32_t>(), A.tok_w0,
+                        c->long_list.as<uint32_t>(), c->long_count.as<uint32_t>(), S, c->hist1.as<unsigned long long>(),
+                        c->rec_a.as<unsigned long long>());
                     const uint32_t dgrid = (uint32_t)std::min<size_t>(nbk, 256u * 4u);
                     k_key_dedupe<<<dgrid, 256, 0, c->stream>>>(c->bucket_off.as<unsigned long long>(), (uint32_t)nbk,
                                                                c->rec_a.as<unsigned long long>(),
@@ -531,9 +572,9 @@ void sage_destroy(sage_ctx* c) {
     collect_events(c);
     for (auto e : c->ev_free) (void)hipEventDestroy(e);
     DevBuf* all[] = {&c->buckets, &c->keys, &c->byte_id, &c->bloom, &c->corpus, &c->rem, &c->line_off, &c->emb, &c->M, &c->ntok,
-                     &c->tokoff, &c->tile_sums, &c->grand_total, &c->tok_w0, &c->tok_pos, &c->set, &c->seg_line_rel,
+                     &c->tokoff, &c->tile_sums, &c->grand_total, &c->tok_w0, &c->occ_pos, &c->set, &c->seg_line_rel,
                      &c->seg_tok_off, &c->set_base, &c->set_mask, &c->seg_pairs, &c->desc, &c->gcache, &c->hist1, &c->bucket_off, &c->rec_a, &c->rec_b, &c->nocc, &c->occoff, &c->occ_tok,
-                     &c->np_ab, &c->dot_off, &c->dots, &c->pool, &c->pool_cursor, &c->emb32, &c->inexact, &c->inex_list, &c->inex_count, &c->ex_ids, &c->ex_starts, &c->ex_widths, &c->loss,
+                     &c->np_ab, &c->dot_off, &c->dots, &c->pool, &c->pool_cursor, &c->emb32, &c->inexact, &c->inex_list, &c->inex_count, &c->long_list, &c->long_count, &c->ex_ids, &c->ex_starts, &c->ex_widths, &c->loss,
                      &c->occ, &c->hist, &c->stats, &c->flags};
     for (DevBuf* b : all) release(*b);
     (void)hipStreamDestroy(c->stream);
@@ -630,6 +671,8 @@ int sage_set_corpus(sage_ctx* c, const uint8_t* bytes, const int64_t* line_offse
     if (nbytes) HIP_TRY(c, hipMemcpy(c->corpus.p, bytes, (size_t)nbytes, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->line_off.p, line_offsets, (size_t)(n_lines + 1) * 8, hipMemcpyHostToDevice));
     c->h_line_off.assign(line_offsets, line_offsets + n_lines + 1);
+    c->max_line_bytes = 0;
+    for (int64_t l = 0; l < n_lines; ++l) c->max_line_bytes = std::max(c->max_line_bytes, line_offsets[l + 1] - line_offsets[l]);
     c->n_lines = n_lines;
     c->nbytes = nbytes;
     if (nbytes) {
@@ -668,7 +711,10 @@ int sage_set_embeddings(sage_ctx* c, const double* emb, int64_t rows, int32_t di
             dst[d] = (float)src[d];
             exact = exact && ((double)dst[d] == src[d]);   // false for NaN: such rows keep their float64 form
         }
-        if (!exact) { bitmap[(size_t)r >> 5] |= 1u << (r & 31); ++n_inexact; }
+        if (!exact) {
+            bitmap[(size_t)r >> 5] |= 1u << (r & 31); ++n_inexact;
+            for (int d = 0; d < dim; ++d) dst[d] = std::numeric_limits<float>::quiet_NaN();   // marks the row for k_logsig
+        }
     }
     c->n_inexact = n_inexact;
     c->use_f32 = (c->score_mode == 0 && n_inexact * 2 <= rows) || (c->score_mode == 2 && n_inexact < rows);

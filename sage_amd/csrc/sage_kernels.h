@@ -121,7 +121,8 @@ __global__ __launch_bounds__(256) void k_match(const uint8_t* __restrict__ corpu
         }
         if (hit) { id2 = id1; len2 = len1; id1 = hid; len1 = (uint32_t)j; }
     }
-    M[rel] = make_uint2(id1 | (len1 << 20), id2 | (len2 << 20));
+    const uint32_t ends1 = len1 == (uint32_t)rem[blk0 + tid] ? 0x80000000u : 0u;
+    M[rel] = make_uint2(id1 | (len1 << 20) | ends1, id2 | (len2 << 20));
 }
 
 // ----------------------------------------------------------------------------------------------------------
@@ -336,7 +337,8 @@ __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ 
         if (top.hits == 0u) { top.id1 = idb; top.len1 = 1; }
         else if (top.hits == 1u) { top.id2 = idb; top.len2 = 1; }
         // streamed once: keep it out of the way of the table and key planes in L2
-        __builtin_nontemporal_store((uint64_t)(top.id1 | (top.len1 << 20)) | ((uint64_t)(top.id2 | (top.len2 << 20)) << 32),
+        const uint32_t ends1 = top.len1 == rm ? 0x80000000u : 0u;
+        __builtin_nontemporal_store((uint64_t)(top.id1 | (top.len1 << 20) | ends1) | ((uint64_t)(top.id2 | (top.len2 << 20)) << 32),
                                     reinterpret_cast<uint64_t*>(M + rel));
     }
 }
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(256) void k_walk_write(const int64_t* __restrict__ 
                                                     uint32_t n_lines, int64_t pos0, const uint2* __restrict__ M,
                                                     const uint32_t* __restrict__ tok_off,
                                                     const uint32_t* __restrict__ occ_off,
-                                                    uint32_t* __restrict__ tok_w0, uint32_t* __restrict__ tok_pos,
+                                                    uint32_t* __restrict__ tok_w0, uint32_t* __restrict__ occ_pos,
                                                     uint32_t* __restrict__ occ_tok,
                                                     int32_t* __restrict__ ex_ids, int32_t* __restrict__ ex_starts,
                                                     int32_t* __restrict__ ex_widths) {
@@ -387,8 +389,7 @@ __global__ __launch_bounds__(256) void k_walk_write(const int64_t* __restrict__ 
         } else {
             const uint32_t after = nt - 1u - c;
             tok_w0[t] = SAGE_M_ID(m) | ((c < 3u ? c : 3u) << 20) | ((after < 3u ? after : 3u) << 22);
-            tok_pos[t] = p;
-            if (SAGE_M_LEN(m) > 1u) occ_tok[o++] = t;   // compact list of the tokens that get ablated
+            if (SAGE_M_LEN(m) > 1u) { occ_tok[o] = t; occ_pos[o] = p; ++o; }   // compact list of the tokens that get ablated
         }
         p += SAGE_M_LEN(m);
         ++t; ++c;
@@ -473,100 +474,12 @@ __global__ void k_gather_u32(const uint32_t* __restrict__ src, const uint32_t* _
     if (i < n) dst[i] = src[idx[i]];
 }
 
-// ----------------------------------------------------------------------------------------------------------
-// The occurrence walker: for base token t with width > 1 it generates, one element per call, first the
-// ABLATED window  [left pads] x1..xk [right pads]  and then the BASE window  [left pads] b1..bm [right pads]
-// of model.py:168-232.  Both K2b (integer counts) and K3 (f64 score) are driven by it, so the two can never
-// disagree about an occurrence.  Everything is read from the match table M, the compact token arrays and rem.
-// ----------------------------------------------------------------------------------------------------------
+// What the ablation walk (walk_occurrence, sage_kernels2.h) reads: the match table M and the compact token arrays.
 struct WalkArrays {
     const uint2* M;
-    const uint8_t* rem;       // already offset to the batch base
+    uint32_t n_pos;           // positions of the batch (entries of M)
     const uint32_t* tok_w0;
-    const uint32_t* tok_pos;
-};
-
-struct Walker {
-    enum State : int { A_L2, A_L1, A_X1, A_X, A_R1, A_R2, B_L2, B_L1, B_B, B_R1, B_R2, DONE };
-    int state;
-    uint32_t a, p0, q, bcur, bspan, idL1, idL2, r1, r2, k;
-    uint2 m0;
-    int pl, pr;
-    bool never;
-
-    // returns false if token t is a single byte (no ablation, model.py:170)
-    __device__ __forceinline__ bool init(const WalkArrays& A, uint32_t t) {
-        const uint32_t w0 = A.tok_w0[t];
-        k = 0;
-        p0 = A.tok_pos[t];
-        m0 = A.M[p0];
-        if (SAGE_M_LEN(m0.x) <= 1u) { state = DONE; return false; }
-        a = SAGE_T_ID(w0);
-        const uint32_t loc3 = SAGE_T_LOC3(w0);
-        pl = loc3 < 2u ? (int)loc3 : 2;                       // padleft = min(pad, loc), model.py:218
-        idL1 = pl >= 1 ? SAGE_T_ID(A.tok_w0[t - 1]) : 0u;
-        idL2 = pl >= 2 ? SAGE_T_ID(A.tok_w0[t - 2]) : 0u;
-        k = 0; pr = 0; never = false; r1 = r2 = 0; q = 0;
-        bcur = p0 + SAGE_M_LEN(m0.x);                         // start of base token loc+1 (or the line end)
-        bspan = p0;
-        state = pl == 2 ? A_L2 : (pl == 1 ? A_L1 : A_X1);
-        return true;
-    }
-    __device__ __forceinline__ int first_base_state() const { return pl == 2 ? B_L2 : (pl == 1 ? B_L1 : B_B); }
-
-    // Produces the next window element.  `fresh` = +1 / -1 when this element opens the ablated / base window.
-    // Returns false when the occurrence is finished (no element produced).
-    __device__ __forceinline__ bool next(const WalkArrays& A, uint32_t& id, bool& centre, int& fresh) {
-        fresh = 0;
-        switch (state) {
-        case A_L2: id = idL2; centre = false; fresh = +1; state = A_L1; return true;
-        case A_L1: id = idL1; centre = false; fresh = (pl == 1) ? +1 : 0; state = A_X1; return true;
-        case A_X1:  // first piece: longest key of at most width-1 bytes = second-longest match (model.py:176-182)
-            id = SAGE_M_ID(m0.y); centre = true; fresh = (pl == 0) ? +1 : 0;
-            q = p0 + SAGE_M_LEN(m0.y); k = 1; state = A_X; return true;
-        case A_X: {  // ordinary greedy steps until a base-token start or the line end (model.py:185-202)
-            const uint32_t mq = A.M[q].x;
-            const uint32_t lq = SAGE_M_LEN(mq);
-            id = SAGE_M_ID(mq); centre = true; ++k;
-            if (lq == (uint32_t)A.rem[q]) {  // reached the line end: beyond = n, no right pads (model.py:194-196)
-                never = true; pr = 0; state = first_base_state();
-            } else {
-                q += lq;
-                // advance along the base chain: is q a base-token start?  (on_base, model.py:163-165,200)
-                while (bcur < q) bcur += SAGE_M_LEN(A.M[bcur].x);
-                if (bcur == q) {
-                    const uint32_t m1 = A.M[q].x;
-                    r1 = SAGE_M_ID(m1);
-                    const uint32_t l1 = SAGE_M_LEN(m1);
-                    if (l1 == (uint32_t)A.rem[q]) pr = 1;          // padright = min(pad, ntok - beyond)
-                    else { pr = 2; r2 = SAGE_M_ID(A.M[q + l1].x); }
-                    state = A_R1;
-                }
-            }
-            return true;
-        }
-        case A_R1: id = r1; centre = false; state = pr == 2 ? A_R2 : first_base_state(); return true;
-        case A_R2: id = r2; centre = false; state = first_base_state(); return true;
-        case B_L2: id = idL2; centre = false; fresh = -1; state = B_L1; return true;
-        case B_L1: id = idL1; centre = false; fresh = (pl == 1) ? -1 : 0; state = B_B; return true;
-        case B_B: {  // base span ids[loc:beyond] (model.py:213); never-rejoined => to the end of the line
-            if (bspan == p0) fresh = (pl == 0) ? -1 : 0;
-            const uint32_t mb = A.M[bspan].x;
-            const uint32_t lb = SAGE_M_LEN(mb);
-            id = SAGE_M_ID(mb); centre = true;
-            if (never) {
-                if (lb == (uint32_t)A.rem[bspan]) state = DONE; else bspan += lb;
-            } else {
-                bspan += lb;
-                if (bspan == q) state = B_R1;
-            }
-            return true;
-        }
-        case B_R1: id = r1; centre = false; state = pr == 2 ? B_R2 : DONE; return true;
-        case B_R2: id = r2; centre = false; state = DONE; return true;
-        default: return false;
-        }
-    }
+    const uint32_t* occ_pos;  // byte position of every ablated occurrence
 };
 
 // ----------------------------------------------------------------------------------------------------------

@@ -8,6 +8,7 @@
 #include "sage_kernels.h"
 
 #define DESC_LDS_STRIDE 17  // 16 words + 1 pad: conflict-free per-thread row writes
+#define DESC_SPAN 3072      // corpus positions of the match table one k_describe tile stages in LDS
 enum { FLAG_POOL_FULL = 3 };
 
 // ----------------------------------------------------------------------------------------------------------
@@ -55,25 +56,99 @@ __device__ __forceinline__ Win win_decode(uint32_t h, uint32_t w2, uint32_t w3) 
     w.L = w.pl + w.k + w.pr;
     return w;
 }
-// number of position pairs of the ablated window (model.py:129-136): element j pairs with j-1 and j-2 when either
-// end lies in the centre [pl, pl+k)
-__device__ __forceinline__ uint32_t win_ablated_pairs(uint32_t pl, uint32_t k, uint32_t pr) {
-    const uint32_t L = pl + k + pr;
-    // all distance-1 and distance-2 pairs, minus those that join two pads on the same side
-    uint32_t n = (L - 1u) + (L >= 2u ? L - 2u : 0u);
-    n -= (pl == 2u ? 1u : 0u) + (pr == 2u ? 1u : 0u);   // (l2,l1) and (r1,r2) at distance 1; no pad-pad pair at distance 2
-    return n;                                            // (a left and a right pad are never within 2 of each other: k >= 2)
-}
-
 #ifndef SAGE_NI
 #define SAGE_NI 2   // window ids in flight in front of the row ring of k_dots
 #endif
 
 // ----------------------------------------------------------------------------------------------------------
-// k_describe: one thread per ablated occurrence walks it (model.py:168-232) once.
+// The ablation walk of one occurrence (model.py:168-232), written as straight phases so that the lanes of a wave run
+// the same code and differ only in trip counts (an element-at-a-time state machine makes every lane pay for every
+// state any lane is in):
+//   left pads (model.py:218-219)  ->  first piece = second-longest match at the token start (model.py:176-182)
+//   ->  greedy pieces until one ends on a base-token start or at the line end (model.py:185-202; the line end is the
+//       `beyond = n` case: no right pads, base span to the end of the line)
+//   ->  right pads (model.py:220-223); the base span [loc, beyond) is counted along the way.
+// emit(id) receives the ablated window in order; returning false from emit abandons the walk (window too long).
+// ----------------------------------------------------------------------------------------------------------
+struct Ablation {
+    uint32_t a;          // ablated id
+    uint32_t k, m;       // pieces, base tokens in the span
+    uint32_t pl, pr;     // pads actually present
+    bool never;          // the walk ran into the line end
+    bool complete;       // false when emit() stopped it
+};
+
+// ldx(p) returns M[p].x; the kernels pass a loader that serves a staged span from LDS.
+template <class LoadX, class Emit>
+__device__ __forceinline__ Ablation walk_occurrence(const WalkArrays& A, uint32_t t, uint32_t p0, LoadX&& ldx, Emit&& emit) {
+    Ablation r;
+    const uint32_t w0 = A.tok_w0[t];
+    const uint2 m0 = A.M[p0];
+    r.a = SAGE_T_ID(w0);
+    const uint32_t loc3 = SAGE_T_LOC3(w0);
+    r.pl = loc3 < 2u ? loc3 : 2u;                              // padleft = min(pad, loc), model.py:218
+    r.k = 0; r.m = 1; r.pr = 0; r.never = false; r.complete = false;
+    if (r.pl == 2u && !emit(SAGE_T_ID(A.tok_w0[t - 2]))) return r;
+    if (r.pl >= 1u && !emit(SAGE_T_ID(A.tok_w0[t - 1]))) return r;
+    // first piece: longest key of at most width-1 bytes = the second-longest match
+    if (!emit(SAGE_M_ID(m0.y))) return r;
+    r.k = 1;
+    uint32_t q = p0 + SAGE_M_LEN(m0.y);
+    uint32_t bcur = p0 + SAGE_M_LEN(m0.x);                     // start of the next base token not yet in the span
+    bool blast = SAGE_M_ENDS(m0.x) != 0u;                      // the last counted base token ends the line
+    bool rejoined = false;
+    for (;;) {
+        const uint32_t mq = ldx(q);
+        if (!emit(SAGE_M_ID(mq))) return r;
+        ++r.k;
+        if (SAGE_M_ENDS(mq)) { r.never = true; break; }        // beyond = n (model.py:194-196)
+        q += SAGE_M_LEN(mq);
+        while (bcur < q) {                                     // on_base: is q a base-token start? (model.py:163-165,200)
+            const uint32_t mb = ldx(bcur);
+            blast = SAGE_M_ENDS(mb) != 0u;
+            bcur += SAGE_M_LEN(mb); ++r.m;
+        }
+        if (bcur == q) { rejoined = true; break; }
+    }
+    if (rejoined) {
+        const uint32_t m1 = ldx(q);
+        if (!emit(SAGE_M_ID(m1))) return r;
+        if (SAGE_M_ENDS(m1)) {
+            r.pr = 1;                                          // padright = min(pad, ntok - beyond)
+        } else {
+            r.pr = 2;
+            if (!emit(SAGE_M_ID(ldx(q + SAGE_M_LEN(m1))))) return r;
+        }
+    } else {
+        while (!blast) {                                       // base span runs to the end of the line
+            const uint32_t mb = ldx(bcur);
+            blast = SAGE_M_ENDS(mb) != 0u;
+            bcur += SAGE_M_LEN(mb); ++r.m;
+        }
+    }
+    r.complete = true;
+    return r;
+}
+
+// Position pairs at distance 1 or 2 of a window [pl pads | c centre elements | pr pads] with at least one end in
+// the centre (model.py:129-136), c >= 1.
+__device__ __forceinline__ uint32_t window_pairs(uint32_t pl_, uint32_t c_, uint32_t pr_) {
+    const int pl = (int)pl_, c = (int)c_, pr = (int)pr_;
+    const int d1 = (c - 1) + (pl >= 1 ? 1 : 0) + (pr >= 1 ? 1 : 0);
+    const int fwd = max(0, min(c, c + pr - 2));                                   // j in the centre, partner j+2
+    const int bwd = max(0, min(pl - 1, pl + c - 3) - max(0, pl - 2) + 1);         // j a left pad, j+2 in the centre
+    return (uint32_t)(d1 + fwd + bwd);
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// k_describe: one thread per ablated occurrence walks it once.
 //   -> descriptor, ablated_sizes histogram, occurrences per id, position pairs per count segment, number of
 //      ablated-window pairs per occurrence (offsets of its dots), step statistics.
+//   LONG = false  every occurrence; a window that needs more than the 15 inline ids (or a base span the header cannot
+//                 hold) is abandoned and goes on the long list (one atomic per wave);
+//   LONG = true   one thread per long-list entry: counting walk, pool allocation, second walk that writes the ids.
 // ----------------------------------------------------------------------------------------------------------
+template <bool LONG>
 __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* __restrict__ occ_tok, uint32_t n_occ,
                                                   SegPlan S, uint4* __restrict__ desc, uint32_t* __restrict__ npairs_ab,
                                                   uint32_t* __restrict__ pool, uint32_t* __restrict__ pool_cursor,
@@ -81,9 +156,9 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
                                                   unsigned long long* __restrict__ occ,
                                                   unsigned long long* __restrict__ hist, uint32_t hist_len,
                                                   unsigned long long* __restrict__ stats, uint32_t* __restrict__ flags,
-                                                  const uint32_t* __restrict__ inexact, uint32_t* __restrict__ inex_list,
-                                                  uint32_t* __restrict__ inex_count) {
-    __shared__ uint32_t rows[256 * DESC_LDS_STRIDE];
+                                                  uint32_t* __restrict__ long_list, uint32_t* __restrict__ long_count) {
+    __shared__ uint32_t rows[LONG ? 1 : 256 * DESC_LDS_STRIDE];
+    __shared__ uint32_t span[LONG ? 1 : DESC_SPAN];   // M[P0 .. P0 + DESC_SPAN).x of the tile: the walks read it from LDS
     __shared__ unsigned int lhist[32];
     __shared__ uint32_t occ_id[ACC_SLOTS];
     __shared__ uint32_t occ_n[ACC_SLOTS];
@@ -91,103 +166,121 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
     for (uint32_t i = threadIdx.x; i < ACC_SLOTS; i += 256) { occ_id[i] = ACC_EMPTY; occ_n[i] = 0; }
     __syncthreads();
     unsigned long long n_rows = 0, n_pairs = 0;
-    const uint32_t n_round = (n_occ + 255u) & ~255u;
-    uint32_t* my = rows + threadIdx.x * DESC_LDS_STRIDE;
+    const uint32_t n_items = LONG ? *long_count : n_occ;
+    const uint32_t n_round = (n_items + 255u) & ~255u;
+    uint32_t* my = rows + (LONG ? 0 : threadIdx.x * DESC_LDS_STRIDE);
+    const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t base = blockIdx.x * 256u; base < n_round; base += gridDim.x * 256u) {
-        const uint32_t o = base + threadIdx.x;
-        const bool live = o < n_occ;
+        const uint32_t item = base + threadIdx.x;
+        const bool live = item < n_items;
+        const uint32_t o = !live ? 0u : (LONG ? long_list[item] : item);
+        uint32_t P0 = 0;
+        if (!LONG) {
+            // 256 consecutive occurrences cover ~1.5 KB of text; their walks stay within a few hundred bytes of it.
+            // Every dependent step of a walk is then an LDS read instead of an L2 round trip.
+            P0 = A.occ_pos[base];
+            for (uint32_t i = threadIdx.x; i < DESC_SPAN; i += 256u) span[i] = (P0 + i) < A.n_pos ? A.M[P0 + i].x : 0u;
+            __syncthreads();
+        }
+        auto ldx = [&](uint32_t p) -> uint32_t {
+            const uint32_t d = p - P0;
+            if (!LONG && d < (uint32_t)DESC_SPAN) return span[d];
+            return A.M[p].x;
+        };
         const uint32_t t = live ? occ_tok[o] : 0u;
+        const uint32_t p0 = live ? A.occ_pos[o] : 0u;
         const uint32_t seg = live ? find_segment(S, t) : 0xFFFFFFFFu;
         unsigned long long my_pairs = 0;
-        uint32_t inex = 0;   // a row of the ablated window is flagged in the `inexact` bitmap (float32 fast path only)
+        bool is_long = false;
         if (live) {
-            Walker w;
-            w.init(A, t);
-            uint32_t id, L = 0, m = 0, ab_pairs = 0;
-            bool c, c1 = false, c2 = false, base_window = false;
-            int have = 0, fresh;
-            while (w.next(A, id, c, fresh)) {
-                if (fresh) { have = 0; base_window = fresh < 0; }
-                uint32_t np = 0;
-                if (have >= 1 && (c || c1)) ++np;
-                if (have >= 2 && (c || c2)) ++np;
-                if (!base_window) {
-                    ++n_rows;
-                    if (L < SAGE_DESC_MAXWIN) my[1 + L] = id;
-                    if (inexact) inex |= (inexact[id >> 5] >> (id & 31u)) & 1u;
+            uint32_t L = 0;
+            Ablation w;
+            if (!LONG) {
+                w = walk_occurrence(A, t, p0, ldx, [&](uint32_t id) {
+                    if (L == SAGE_DESC_MAXWIN) return false;     // does not fit: leave it to the long pass
+                    my[1 + L] = id;
                     ++L;
-                    ab_pairs += np;
-                } else if (c) {
-                    ++n_rows; ++m;
-                }
-                my_pairs += np;
-                c2 = c1; c1 = c; ++have;
-            }
-            const bool pooled = L > SAGE_DESC_MAXWIN || m > 0xFFFu;
-            uint32_t hdr = SAGE_DH_VALID | (w.never ? SAGE_DH_NEVER : 0u) | ((uint32_t)w.pl << 24) | ((uint32_t)w.pr << 26) |
-                           (inex ? SAGE_DH_INEXACT : 0u);
-            if (!pooled) {
-                hdr |= w.k | (m << 12);
+                    return true;
+                });
+                is_long = !w.complete || w.m > 0xFFFu;
             } else {
-                hdr |= SAGE_DH_OVER;
-                const uint32_t at = atomicAdd(pool_cursor, L);
-                my[1] = at; my[2] = w.k; my[3] = m;
-                if (at + L <= pool_cap && at + L >= at) {
-                    Walker w2;       // second walk of a long window: ids straight into the pool
-                    w2.init(A, t);
-                    uint32_t j = 0;
-                    while (w2.next(A, id, c, fresh)) {
-                        if (fresh < 0) break;
-                        pool[at + j++] = id;
-                    }
-                } else {
-                    flags[FLAG_POOL_FULL] = 1;
-                }
+                w = walk_occurrence(A, t, p0, ldx, [&](uint32_t) { ++L; return true; });
             }
-            my[0] = hdr;
-            npairs_ab[o] = ab_pairs;
-            acc_add_u32(occ_id, occ_n, occ, w.a);
-            const uint32_t kk = w.k < hist_len ? w.k : hist_len - 1u;
-            if (kk < 32u) atomicAdd(&lhist[kk], 1u); else atomicAdd(&hist[kk], 1ull);
+            if (is_long) {
+                my[0] = SAGE_DH_VALID | SAGE_DH_OVER;  // placeholder, rewritten by the long pass
+            } else {
+                uint32_t hdr = SAGE_DH_VALID | (w.never ? SAGE_DH_NEVER : 0u) | (w.pl << 24) | (w.pr << 26);
+                if (!LONG) {
+                    my[0] = hdr | w.k | (w.m << 12);
+                } else {
+                    uint32_t at = atomicAdd(pool_cursor, L);
+                    const bool fits = at + L <= pool_cap && at + L >= at;
+                    // no room: the step is redone with a larger pool; until then the window points at the pool's first
+                    // L ids (in bounds: pool_cap >= the longest possible window), so every reader stays in bounds
+                    if (!fits) at = 0;
+                    if (fits) {
+                        uint32_t j = 0;          // second walk of a long window: ids straight into the pool
+                        walk_occurrence(A, t, p0, ldx, [&](uint32_t id) {
+                            pool[at + j++] = id;
+                            return true;
+                        });
+                    } else {
+                        flags[FLAG_POOL_FULL] = 1;
+                    }
+                    hdr |= SAGE_DH_OVER;
+                    uint4* dst = desc + (size_t)o * 4;
+                    dst[0] = make_uint4(hdr, at, w.k, w.m);
+                    dst[1] = make_uint4(0, 0, 0, 0); dst[2] = make_uint4(0, 0, 0, 0); dst[3] = make_uint4(0, 0, 0, 0);
+                }
+                const uint32_t ab_pairs = window_pairs(w.pl, w.k, w.pr);
+                my_pairs = (unsigned long long)ab_pairs + window_pairs(w.pl, w.m, w.pr);
+                n_rows += L + w.m;
+                npairs_ab[o] = ab_pairs;
+                acc_add_u32(occ_id, occ_n, occ, w.a);
+                const uint32_t kk = w.k < hist_len ? w.k : hist_len - 1u;
+                if (kk < 32u) atomicAdd(&lhist[kk], 1u); else atomicAdd(&hist[kk], 1ull);
+            }
         }
         n_pairs += my_pairs;
-        if (inexact) {   // flagged occurrences go on a list for the float64 fix-up pass (one atomic per wave)
-            const unsigned long long bal = __ballot(inex != 0u);
+        if (!LONG) {   // abandoned walks go on the long list (one atomic per wave)
+            const unsigned long long bal = __ballot(is_long);
             if (bal) {
-                const uint32_t lane = threadIdx.x & 63u;
+                const int lead = __ffsll((long long)bal) - 1;
                 uint32_t at = 0;
-                if (lane == (uint32_t)__ffsll((long long)bal) - 1u) {
-                    at = atomicAdd(inex_count, (uint32_t)__popcll(bal));
-                    atomicAdd(&stats[STAT_INEXACT], (unsigned long long)__popcll(bal));
+                if ((int)lane == lead) at = atomicAdd(long_count, (uint32_t)__popcll(bal));
+                at = __shfl(at, lead, 64);
+                if (is_long) long_list[at + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = o;
+            }
+        }
+        {   // pairs per segment: lanes of one segment are summed in the wave, one atomic per (wave, segment)
+            unsigned long long todo = __ballot(my_pairs != 0ull);
+            while (todo) {
+                const int lead = __ffsll((long long)todo) - 1;
+                const uint32_t sk = __shfl(seg, lead, 64);
+                const unsigned long long grp = __ballot(seg == sk && my_pairs != 0ull);
+                unsigned long long v = (seg == sk) ? my_pairs : 0ull;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+                if ((int)lane == lead) atomicAdd(&seg_pairs[sk], v);
+                todo &= ~grp;
+            }
+        }
+        if (!LONG) {
+            __syncthreads();
+            // coalesced write-out of the block's 256 descriptors (4 x 16 B each)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t q = threadIdx.x + 256u * r;      // uint4 index inside the block's tile
+                const uint32_t row = q >> 2, col = (q & 3u) * 4u;
+                if (base + row < n_occ) {
+                    const uint32_t* src = rows + row * DESC_LDS_STRIDE + col;
+                    desc[(size_t)(base + row) * 4 + (q & 3u)] = make_uint4(src[0], src[1], src[2], src[3]);
                 }
-                at = __shfl(at, __ffsll((long long)bal) - 1, 64);
-                if (inex) inex_list[at + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = o;
             }
+            __syncthreads();
         }
-        {   // pairs per segment: one atomic per wave when the wave sits inside one segment (the usual case)
-            const uint32_t seg0 = __shfl(seg, 0, 64);
-            if (__all(seg == seg0 || seg == 0xFFFFFFFFu) && seg0 != 0xFFFFFFFFu) {
-                unsigned long long v = my_pairs;
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
-                if ((threadIdx.x & 63u) == 0 && v) atomicAdd(&seg_pairs[seg0], v);
-            } else if (my_pairs) {
-                atomicAdd(&seg_pairs[seg], my_pairs);
-            }
-        }
-        __syncthreads();
-        // coalesced write-out of the block's 256 descriptors (4 x 16 B each)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const uint32_t q = threadIdx.x + 256u * r;      // uint4 index inside the block's tile
-            const uint32_t row = q >> 2, col = (q & 3u) * 4u;
-            if (base + row < n_occ) {
-                const uint32_t* src = rows + row * DESC_LDS_STRIDE + col;
-                desc[(size_t)(base + row) * 4 + (q & 3u)] = make_uint4(src[0], src[1], src[2], src[3]);
-            }
-        }
-        __syncthreads();
     }
+    __syncthreads();
     if (threadIdx.x < 32 && threadIdx.x < hist_len && lhist[threadIdx.x])
         atomicAdd(&hist[threadIdx.x], (unsigned long long)lhist[threadIdx.x]);
     for (uint32_t i = threadIdx.x; i < ACC_SLOTS; i += 256)
@@ -197,7 +290,7 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
         n_rows += __shfl_down(n_rows, d, 64);
         n_pairs += __shfl_down(n_pairs, d, 64);
     }
-    if ((threadIdx.x & 63u) == 0) {
+    if (lane == 0) {
         if (n_rows) atomicAdd(&stats[STAT_ROWS], n_rows);
         if (n_pairs) atomicAdd(&stats[STAT_PAIRS], n_pairs);
     }
@@ -436,11 +529,17 @@ __global__ __launch_bounds__(256) void k_dots(const uint4* __restrict__ desc, co
 __global__ __launch_bounds__(256) void k_logsig(const uint4* __restrict__ desc, const uint32_t* __restrict__ occ_tok,
                                                 const uint32_t* __restrict__ tok_w0, uint32_t n_occ,
                                                 const uint32_t* __restrict__ dot_off, const double* __restrict__ dots,
-                                                const double2* __restrict__ Gc, double* __restrict__ loss) {
+                                                const double2* __restrict__ Gc, double* __restrict__ loss,
+                                                uint32_t* __restrict__ fix_list, uint32_t* __restrict__ fix_count) {
+    // fix_list != nullptr (float32 row storage): rows that float32 cannot hold are stored as NaN, so an occurrence
+    // whose sum comes out NaN touched one; it is not accumulated but listed for the float64 pass (k_dots on the list,
+    // then k_logsig_list).
     __shared__ uint32_t acc_id[ACC_SLOTS];
     __shared__ double acc_val[ACC_SLOTS];
     __shared__ uint32_t off[LOGSIG_TILE + 1];
     __shared__ double osum[LOGSIG_TILE];
+    __shared__ uint32_t wcnt[5];
+    __shared__ uint32_t obad[LOGSIG_TILE];   // the occurrence has a NaN dot (a row the float32 copy cannot hold)
     for (uint32_t i = threadIdx.x; i < ACC_SLOTS; i += 256) { acc_id[i] = ACC_EMPTY; acc_val[i] = 0.0; }
     const double* Gd = reinterpret_cast<const double*>(Gc);
     for (uint32_t o0 = blockIdx.x * LOGSIG_TILE; o0 < n_occ; o0 += gridDim.x * LOGSIG_TILE) {
@@ -449,6 +548,7 @@ __global__ __launch_bounds__(256) void k_logsig(const uint4* __restrict__ desc, 
         if (threadIdx.x < nt) off[threadIdx.x] = dot_off[o0 + threadIdx.x];
         if (threadIdx.x == 0) off[nt] = dot_off[o0 + nt];   // nt can be 256: there is no thread 256
         osum[threadIdx.x] = 0.0;
+        obad[threadIdx.x] = 0u;
         // phase-2 operands are independent of phase 1: issue their loads first
         const uint32_t o = o0 + threadIdx.x;
         uint4 h = make_uint4(0, 0, 0, 0);
@@ -468,17 +568,25 @@ __global__ __launch_bounds__(256) void k_logsig(const uint4* __restrict__ desc, 
             }
             uint32_t own = lo, nxt = off[own + 1];
             double acc = 0.0;
+            bool bad = false;
             for (; i < iend; ++i) {
                 if (i >= nxt) {
                     unsafeAtomicAdd(&osum[own], acc);
-                    acc = 0.0;
+                    if (bad) obad[own] = 1u;
+                    acc = 0.0; bad = false;
                     do { ++own; nxt = off[own + 1]; } while (i >= nxt);
                 }
-                acc += log_sigmoid(dots[i]);
+                // NaN never enters exp/log1p (their special-case paths are slow and a wave takes them for one lane)
+                const double x = dots[i];
+                const bool isn = x != x;
+                bad = bad || isn;
+                acc += log_sigmoid(isn ? 0.0 : x);
             }
             unsafeAtomicAdd(&osum[own], acc);
+            if (bad) obad[own] = 1u;
         }
         __syncthreads();
+        bool redo = false;
         if (threadIdx.x < nt) {
             const Win w = win_decode(h.x, h.z, h.w);
             const uint32_t a = SAGE_T_ID(tok_w0[t]);
@@ -492,8 +600,75 @@ __global__ __launch_bounds__(256) void k_logsig(const uint4* __restrict__ desc, 
             for (int rel = lo1; rel <= hi1; ++rel) sb += Gd[((size_t)t + rel) * 2];
             for (int rel = lo2; rel <= hi2; ++rel)
                 if ((rel >= 0 && rel <= im - 1) || (rel + 2 >= 0 && rel + 2 <= im - 1)) sb += Gd[((size_t)t + rel) * 2 + 1];
-            acc_add_f64(acc_id, acc_val, loss, a, -2.0 * (osum[threadIdx.x] - sb));
+            const double sum = osum[threadIdx.x];
+            redo = fix_list != nullptr && obad[threadIdx.x] != 0u;
+            // without a fix list a NaN dot is the caller's own NaN: it goes into the loss as the reference's would
+            const double nan_in = (fix_list == nullptr && obad[threadIdx.x] != 0u) ? __builtin_nan("") : 0.0;
+            if (!redo) acc_add_f64(acc_id, acc_val, loss, a, -2.0 * (sum - sb) + nan_in);
         }
+        if (fix_list) {   // one global atomic per tile: rank inside the wave, wave offsets through LDS
+            const unsigned long long bal = __ballot(redo);
+            const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+            if (lane == 0) wcnt[wave] = (uint32_t)__popcll(bal);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const uint32_t tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+                wcnt[4] = tot ? atomicAdd(fix_count, tot) : 0u;
+            }
+            __syncthreads();
+            if (redo) {
+                uint32_t at = wcnt[4];
+                for (uint32_t w = 0; w < wave; ++w) at += wcnt[w];
+                fix_list[at + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = o;
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < ACC_SLOTS; i += 256)
+        if (acc_id[i] != ACC_EMPTY) unsafeAtomicAdd(&loss[acc_id[i]], acc_val[i]);
+}
+
+// The same for the occurrences on a list (their dots recomputed from the float64 matrix): 8 lanes per occurrence.
+__global__ __launch_bounds__(256) void k_logsig_list(const uint4* __restrict__ desc, const uint32_t* __restrict__ occ_tok,
+                                                     const uint32_t* __restrict__ tok_w0,
+                                                     const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count,
+                                                     const uint32_t* __restrict__ dot_off, const double* __restrict__ dots,
+                                                     const double2* __restrict__ Gc, double* __restrict__ loss,
+                                                     unsigned long long* __restrict__ stats) {
+    constexpr int G = 8;
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[STAT_INEXACT], (unsigned long long)*list_count);
+    __shared__ uint32_t acc_id[ACC_SLOTS];
+    __shared__ double acc_val[ACC_SLOTS];
+    for (uint32_t i = threadIdx.x; i < ACC_SLOTS; i += 256) { acc_id[i] = ACC_EMPTY; acc_val[i] = 0.0; }
+    __syncthreads();
+    const uint32_t n = *list_count;
+    const uint32_t gl = threadIdx.x % G;
+    const double* Gd = reinterpret_cast<const double*>(Gc);
+    const uint32_t n_round = (n + 31u) & ~31u;
+    for (uint32_t e0 = blockIdx.x * 32u; e0 < n_round; e0 += gridDim.x * 32u) {
+        const uint32_t e = e0 + threadIdx.x / G;
+        double acc = 0.0;
+        uint32_t a = 0;
+        if (e < n) {
+            const uint32_t o = list[e];
+            const uint4 h = desc[(size_t)o * 4];
+            const Win w = win_decode(h.x, h.z, h.w);
+            const uint32_t t = occ_tok[o];
+            a = SAGE_T_ID(tok_w0[t]);
+            const uint32_t d0 = dot_off[o], d1 = dot_off[o + 1];
+            for (uint32_t i = d0 + gl; i < d1; i += G) acc += log_sigmoid(dots[i]);
+            const int im = (int)w.m, ipl = (int)w.pl, ipr = (int)w.pr;
+            const int lo1 = ipl >= 1 ? -1 : 0, hi1 = im - 2 + (ipr >= 1 ? 1 : 0);
+            const int lo2 = -ipl, hi2 = im + ipr - 3;
+            double sb = 0.0;
+            for (int rel = lo1 + (int)gl; rel <= hi1; rel += G) sb += Gd[((size_t)t + rel) * 2];
+            for (int rel = lo2 + (int)gl; rel <= hi2; rel += G)
+                if ((rel >= 0 && rel <= im - 1) || (rel + 2 >= 0 && rel + 2 <= im - 1)) sb += Gd[((size_t)t + rel) * 2 + 1];
+            acc -= sb;
+        }
+#pragma unroll
+        for (int mm = G / 2; mm >= 1; mm >>= 1) acc += __shfl_xor(acc, mm, G);
+        if (gl == 0 && e < n) acc_add_f64(acc_id, acc_val, loss, a, -2.0 * acc);
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < ACC_SLOTS; i += 256)

@@ -19,11 +19,13 @@
 
 // Calls f(lo, hi) for every position pair of the occurrence's two windows (model.py:115-136 via descriptors).
 // d = the 16 descriptor words in registers; long windows stream their ids from the pool.
-template <class F>
+// POOLED_TOO = false: the caller has already set pooled occurrences aside (k_key_partition_long handles them).
+template <bool POOLED_TOO, class F>
 __device__ __forceinline__ void keys_from_desc(const uint32_t (&d)[16], const uint32_t* __restrict__ pool,
                                                const uint32_t* __restrict__ tok_w0, uint32_t t, F&& f) {
     const Win w = win_decode(d[0], d[2], d[3]);
     const uint32_t pl = w.pl, k = w.k, m = w.m, pr = w.pr, L = w.L;
+    if (!POOLED_TOO && w.pooled) return;
     if (!w.pooled) {
 #pragma unroll
         for (int j = 1; j < SAGE_DESC_MAXWIN; ++j) {
@@ -37,7 +39,7 @@ __device__ __forceinline__ void keys_from_desc(const uint32_t (&d)[16], const ui
                 }
             }
         }
-    } else {
+    } else if (POOLED_TOO) {
         const uint32_t* ids = pool + d[1];
         uint32_t p1 = 0, p2 = 0;
         for (uint32_t j = 0; j < L; ++j) {
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(256) void k_count_sets(const uint4* __restrict__ de
         const uint32_t seg = find_segment(S, t);
         const uint64_t base = S.set_base[seg], mask = S.set_mask[seg];
         const uint32_t a = SAGE_T_ID(tok_w0[t]);
-        keys_from_desc(d, pool, tok_w0, t, [&](uint32_t lo, uint32_t hi) {
+        keys_from_desc<true>(d, pool, tok_w0, t, [&](uint32_t lo, uint32_t hi) {
             const uint32_t nw = set_insert(set, base, mask, make_key(a, lo, hi), flags);
             n_distinct += nw ? (lo == hi ? 1u : 2u) : 0u;
         });
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256) void k_key_partition(const uint4* __restrict__
         const bool local = live && (seg - s0) < 2u;
         __syncthreads();
         if (live) {
-            keys_from_desc(d, pool, tok_w0, t, [&](uint32_t lo, uint32_t hi) {
+            keys_from_desc<false>(d, pool, tok_w0, t, [&](uint32_t lo, uint32_t hi) {
                 const uint64_t key = make_key(a, lo, hi);
                 const uint32_t b1 = (uint32_t)sage_mix64(key) & (NB1 - 1);
                 if (local) atomicAdd(&cnt[seg - s0][b1], 1u);
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(256) void k_key_partition(const uint4* __restrict__
         if (MODE == 1) {
             __syncthreads();
             if (local) {
-                keys_from_desc(d, pool, tok_w0, t, [&](uint32_t lo, uint32_t hi) {
+                keys_from_desc<false>(d, pool, tok_w0, t, [&](uint32_t lo, uint32_t hi) {
                     const uint64_t key = make_key(a, lo, hi);
                     const uint32_t b1 = (uint32_t)sage_mix64(key) & (NB1 - 1);
                     const uint32_t r = atomicAdd(&cnt[seg - s0][b1], 1u);
@@ -152,6 +154,100 @@ __global__ __launch_bounds__(256) void k_key_partition(const uint4* __restrict__
             }
         }
         __syncthreads();
+    }
+}
+
+// ---- passes 1 and 2 for the long (pooled) occurrences: a WAVE per occurrence, lanes stride over the window --------
+// A wave takes LONG_CHUNK consecutive list entries, splits them into runs of one segment (nearly always a single
+// run: the list is in rough corpus order), counts the run's keys per bucket in its own LDS counters, reserves the
+// bucket ranges with one global atomic per non-empty bucket, and (MODE 1) walks the run again to write the keys.
+#define LONG_CHUNK 16
+template <class F>
+__device__ __forceinline__ void keys_of_long(const uint4* __restrict__ desc, const uint32_t* __restrict__ pool,
+                                             const uint32_t* __restrict__ tok_w0, uint32_t o, uint32_t t, uint32_t lane, F&& f) {
+    const uint4 h = desc[(size_t)o * 4];
+    const Win w = win_decode(h.x, h.z, h.w);
+    const uint32_t pl = w.pl, k = w.k, m = w.m, pr = w.pr, L = w.L;
+    const uint32_t* ids = pool + h.y;
+    for (uint32_t j = lane; j < L; j += 64u) {
+        const uint32_t id = ids[j];
+        const bool c = j >= pl && j < pl + k;
+        if (j >= 1u) { const uint32_t p1 = ids[j - 1]; const bool c1 = (j - 1) >= pl && (j - 1) < pl + k; if (c || c1) f(min(id, p1), max(id, p1)); }
+        if (j >= 2u) { const uint32_t p2 = ids[j - 2]; const bool c2 = (j - 2) >= pl && (j - 2) < pl + k; if (c || c2) f(min(id, p2), max(id, p2)); }
+    }
+    const uint32_t w0 = t - pl, w1 = t + m + pr;  // base window tokens [w0, w1), centre [t, t+m)
+    for (uint32_t i = w0 + lane; i < w1; i += 64u) {
+        const uint32_t id = SAGE_T_ID(tok_w0[i]);
+        const bool c = i >= t && i < t + m;
+        if (i >= w0 + 1) { const uint32_t p1 = SAGE_T_ID(tok_w0[i - 1]); const bool c1 = (i - 1) >= t && (i - 1) < t + m; if (c || c1) f(min(id, p1), max(id, p1)); }
+        if (i >= w0 + 2) { const uint32_t p2 = SAGE_T_ID(tok_w0[i - 2]); const bool c2 = (i - 2) >= t && (i - 2) < t + m; if (c || c2) f(min(id, p2), max(id, p2)); }
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_key_partition_long(const uint4* __restrict__ desc, const uint32_t* __restrict__ pool,
+                                                            const uint32_t* __restrict__ occ_tok,
+                                                            const uint32_t* __restrict__ tok_w0,
+                                                            const uint32_t* __restrict__ long_list,
+                                                            const uint32_t* __restrict__ long_count, SegPlan S,
+                                                            unsigned long long* __restrict__ counters,
+                                                            unsigned long long* __restrict__ rec) {
+    static_assert(NB1 == 64, "one lane per coarse bucket");
+    __shared__ unsigned int cnt[4][NB1];
+    __shared__ unsigned long long gbase[4][NB1];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t n = *long_count;
+    const uint32_t n_chunks = (n + LONG_CHUNK - 1) / LONG_CHUNK;
+    for (uint32_t chunk = blockIdx.x * 4u + wave; chunk < n_chunks; chunk += gridDim.x * 4u) {
+        const uint32_t e0 = chunk * LONG_CHUNK, e1 = min(n, e0 + LONG_CHUNK);
+        // lane i < LONG_CHUNK holds entry e0 + i: occurrence, token, segment
+        uint32_t my_o = 0, my_t = 0, my_seg = 0xFFFFFFFFu;
+        if (e0 + lane < e1) {
+            my_o = long_list[e0 + lane];
+            my_t = occ_tok[my_o];
+            my_seg = find_segment(S, my_t);
+        }
+        uint32_t e = e0;
+        while (e < e1) {
+            const uint32_t seg = __shfl(my_seg, (int)(e - e0), 64);
+            uint32_t f = e + 1;
+            while (f < e1 && __shfl(my_seg, (int)(f - e0), 64) == seg) ++f;
+            cnt[wave][lane] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t g = e; g < f; ++g) {
+                const uint32_t o = __shfl(my_o, (int)(g - e0), 64), t = __shfl(my_t, (int)(g - e0), 64);
+                const uint32_t a = SAGE_T_ID(tok_w0[t]);
+                keys_of_long(desc, pool, tok_w0, o, t, lane, [&](uint32_t lo, uint32_t hi) {
+                    atomicAdd(&cnt[wave][(uint32_t)sage_mix64(make_key(a, lo, hi)) & (NB1 - 1)], 1u);
+                });
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            {
+                const uint32_t nb = cnt[wave][lane];
+                unsigned long long old = 0;
+                if (nb) old = atomicAdd(&counters[(size_t)seg * NB1 + lane], (unsigned long long)nb);
+                if (MODE == 1) { gbase[wave][lane] = old; cnt[wave][lane] = 0; }
+            }
+            if (MODE == 1) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t g = e; g < f; ++g) {
+                    const uint32_t o = __shfl(my_o, (int)(g - e0), 64), t = __shfl(my_t, (int)(g - e0), 64);
+                    const uint32_t a = SAGE_T_ID(tok_w0[t]);
+                    keys_of_long(desc, pool, tok_w0, o, t, lane, [&](uint32_t lo, uint32_t hi) {
+                        const uint64_t key = make_key(a, lo, hi);
+                        const uint32_t b1 = (uint32_t)sage_mix64(key) & (NB1 - 1);
+                        const uint32_t r = atomicAdd(&cnt[wave][b1], 1u);
+                        rec[gbase[wave][b1] + r] = key;
+                    });
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            e = f;
+        }
     }
 }
 
