@@ -404,6 +404,7 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
             }
             SegPlan S{c->seg_tok_off.as<uint32_t>(), c->set_base.as<uint64_t>(), c->set_mask.as<uint64_t>(), nsb};
             const uint32_t cgrid = std::min<uint32_t>(cdiv(n_occ, 256), 256u * 16u);
+            const uint32_t pgrid = std::min<uint32_t>(cdiv(n_occ, PART_TILE), 256u * 16u);
             const uint32_t lgrid = std::min<uint32_t>(cdiv(n_occ, 256), 256u * 8u);   // long-list kernels (grid-stride)
             if ((rc = ensure(c, c->long_list, (size_t)n_occ * 4))) return rc;
             if ((rc = ensure(c, c->long_count, 4))) return rc;
@@ -435,7 +436,7 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
                 HIP_TRY(c, hipMemsetAsync(c->hist1.p, 0, nbk * 8, c->stream));
                 {
                     Prof p(c, SAGE_K_COUNT);
-                    k_key_partition<0><<<cgrid, 256, 0, c->stream>>>(c->desc.as<uint4>(), c->pool.as<uint32_t>(),
+                    k_key_partition<0><<<pgrid, PART_TILE, 0, c->stream>>>(c->desc.as<uint4>(), c->pool.as<uint32_t>(),
                                                                      c->occ_tok.as<uint32_t>(), A.tok_w0, n_occ, S,
                                                                      c->hist1.as<unsigned long long>(), nullptr);
                     k_key_partition_long<0><<<lgrid, 256, 0, c->stream>>>(
@@ -455,7 +456,7 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
                 HIP_TRY(c, hipMemcpyAsync(c->hist1.p, boff.data(), nbk * 8, hipMemcpyHostToDevice, c->stream));  // cursors
                 {
                     Prof p(c, SAGE_K_COUNT);
-                    k_key_partition<1><<<cgrid, 256, 0, c->stream>>>(c->desc.as<uint4>(), c->pool.as<uint32_t>(),
+                    k_key_partition<1><<<pgrid, PART_TILE, 0, c->stream>>>(c->desc.as<uint4>(), c->pool.as<uint32_t>(),
                                                                      c->occ_tok.as<uint32_t>(), A.tok_w0, n_occ, S,
                                                                      c->hist1.as<unsigned long long>(),
                                                                      c->rec_a.as<unsigned long long>());

@@ -8,6 +8,7 @@
 #include "sage_kernels.h"
 
 #define DESC_LDS_STRIDE 17  // 16 words + 1 pad: conflict-free per-thread row writes
+#define SEG_LDS 128         // count segments of a batch whose pair totals k_describe accumulates in LDS
 #define DESC_SPAN 3072      // corpus positions of the match table one k_describe tile stages in LDS
 enum { FLAG_POOL_FULL = 3 };
 
@@ -158,11 +159,14 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
                                                   unsigned long long* __restrict__ stats, uint32_t* __restrict__ flags,
                                                   uint32_t* __restrict__ long_list, uint32_t* __restrict__ long_count) {
     __shared__ uint32_t rows[LONG ? 1 : 256 * DESC_LDS_STRIDE];
+    __shared__ uint32_t wcnt[5];
+    __shared__ unsigned long long lseg[SEG_LDS];
     __shared__ uint32_t span[LONG ? 1 : DESC_SPAN];   // M[P0 .. P0 + DESC_SPAN).x of the tile: the walks read it from LDS
     __shared__ unsigned int lhist[32];
     __shared__ uint32_t occ_id[ACC_SLOTS];
     __shared__ uint32_t occ_n[ACC_SLOTS];
     if (threadIdx.x < 32) lhist[threadIdx.x] = 0;
+    if (threadIdx.x < SEG_LDS) lseg[threadIdx.x] = 0ull;
     for (uint32_t i = threadIdx.x; i < ACC_SLOTS; i += 256) { occ_id[i] = ACC_EMPTY; occ_n[i] = 0; }
     __syncthreads();
     unsigned long long n_rows = 0, n_pairs = 0;
@@ -242,28 +246,25 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
             }
         }
         n_pairs += my_pairs;
-        if (!LONG) {   // abandoned walks go on the long list (one atomic per wave)
+        if (!LONG) {   // abandoned walks go on the long list: one global atomic per tile (hot counter)
             const unsigned long long bal = __ballot(is_long);
-            if (bal) {
-                const int lead = __ffsll((long long)bal) - 1;
-                uint32_t at = 0;
-                if ((int)lane == lead) at = atomicAdd(long_count, (uint32_t)__popcll(bal));
-                at = __shfl(at, lead, 64);
-                if (is_long) long_list[at + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = o;
+            const uint32_t wave = threadIdx.x >> 6;
+            if (lane == 0) wcnt[wave] = (uint32_t)__popcll(bal);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const uint32_t tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+                wcnt[4] = tot ? atomicAdd(long_count, tot) : 0u;
+            }
+            __syncthreads();
+            if (is_long) {
+                uint32_t at = wcnt[4];
+                for (uint32_t w = 0; w < wave; ++w) at += wcnt[w];
+                long_list[at + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = o;
             }
         }
-        {   // pairs per segment: lanes of one segment are summed in the wave, one atomic per (wave, segment)
-            unsigned long long todo = __ballot(my_pairs != 0ull);
-            while (todo) {
-                const int lead = __ffsll((long long)todo) - 1;
-                const uint32_t sk = __shfl(seg, lead, 64);
-                const unsigned long long grp = __ballot(seg == sk && my_pairs != 0ull);
-                unsigned long long v = (seg == sk) ? my_pairs : 0ull;
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-                if ((int)lane == lead) atomicAdd(&seg_pairs[sk], v);
-                todo &= ~grp;
-            }
+        if (my_pairs) {   // pairs per segment: LDS for the first SEG_LDS segments of the batch, flushed once per workgroup
+            if (seg < (uint32_t)SEG_LDS) atomicAdd(&lseg[seg], my_pairs);
+            else atomicAdd(&seg_pairs[seg], my_pairs);
         }
         if (!LONG) {
             __syncthreads();
@@ -285,6 +286,7 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
         atomicAdd(&hist[threadIdx.x], (unsigned long long)lhist[threadIdx.x]);
     for (uint32_t i = threadIdx.x; i < ACC_SLOTS; i += 256)
         if (occ_n[i]) atomicAdd(&occ[occ_id[i]], (unsigned long long)occ_n[i]);
+    if (threadIdx.x < SEG_LDS && threadIdx.x < S.n_seg && lseg[threadIdx.x]) atomicAdd(&seg_pairs[threadIdx.x], lseg[threadIdx.x]);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         n_rows += __shfl_down(n_rows, d, 64);

@@ -15,6 +15,7 @@
 #define SET_SLOTS 4096   // LDS set capacity (u64 slots, 32 KiB)
 #define SET_FILL 2048    // at most this many records are offered to one set pass (load <= 0.5)
 #define NB2_MAX 256
+#define PART_TILE 256u  // occurrences per k_key_partition tile (one workgroup)
 #define UNR 8          // keys a thread keeps in flight in the streaming loops of k_key_dedupe
 
 // Calls f(lo, hi) for every position pair of the occurrence's two windows (model.py:115-136 via descriptors).
@@ -100,15 +101,15 @@ __global__ __launch_bounds__(256) void k_count_sets(const uint4* __restrict__ de
 // base offset).  A tile of 256 consecutive occurrences touches at most two segments in practice; those go through
 // LDS counters and one global atomic per (tile, bucket); anything else takes one global atomic per key.
 template <int MODE>
-__global__ __launch_bounds__(256) void k_key_partition(const uint4* __restrict__ desc, const uint32_t* __restrict__ pool,
+__global__ __launch_bounds__(PART_TILE) void k_key_partition(const uint4* __restrict__ desc, const uint32_t* __restrict__ pool,
                                                        const uint32_t* __restrict__ occ_tok,
                                                        const uint32_t* __restrict__ tok_w0, uint32_t n_occ, SegPlan S,
                                                        unsigned long long* __restrict__ counters,
                                                        unsigned long long* __restrict__ rec) {
     __shared__ unsigned int cnt[2][NB1];
     __shared__ unsigned long long gbase[2][NB1];
-    const uint32_t n_round = (n_occ + 255u) & ~255u;
-    for (uint32_t base = blockIdx.x * 256u; base < n_round; base += gridDim.x * 256u) {
+    const uint32_t n_round = (n_occ + PART_TILE - 1u) / PART_TILE * PART_TILE;
+    for (uint32_t base = blockIdx.x * PART_TILE; base < n_round; base += gridDim.x * PART_TILE) {
         const uint32_t o = base + threadIdx.x;
         if (threadIdx.x < 2 * NB1) cnt[threadIdx.x / NB1][threadIdx.x % NB1] = 0;
         const uint32_t s0 = find_segment(S, occ_tok[base]);
