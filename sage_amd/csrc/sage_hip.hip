@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -512,7 +513,7 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
             return fail(c, SAGE_E_EMPTY_LINE, "not enough values to unpack (expected 3, got 0)");
         if (flags[FLAG_POOL_FULL]) {
             if (attempt >= 6) return fail(c, SAGE_E_LIMIT, "window-id pool overflowed");
-            c->pool_factor *= 4;   // long ablation chains: redo the step with a larger id pool
+            c->pool_factor = std::max(1, c->pool_factor) * 4;   // long ablation chains: redo the step with a larger id pool
             continue;
         }
         if (flags[FLAG_SET_OVERFLOW]) {
@@ -558,6 +559,8 @@ int sage_create(int device, sage_ctx** out_ctx) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
     }
+    // test hook: start with a smaller id pool so that the overflow-and-redo path can be exercised
+    if (const char* e = std::getenv("SAGE_POOL_FACTOR")) { const int v = std::atoi(e); if (v >= 0 && v <= 64) c->pool_factor = v; }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SAGE_E_HIP; }
     if (hipMalloc(&c->flags.p, FLAG_COUNT * 4) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return SAGE_E_HIP; }
     c->flags.cap = FLAG_COUNT * 4;

@@ -238,3 +238,29 @@ def test_long_windows_vs_oracle():
     eng.set_embeddings(emb)
     _check_step(eng, segment_line_bounds(len(lines), 1, flush=9), tt, ttr, losses, sizes, want_occ=occs)
     eng.close()
+
+
+def test_pool_overflow_is_redone(monkeypatch):
+    """Long windows keep their ids in a pool sized from the occurrence count; when it overflows the step is redone
+    with a larger pool (and every reader stays in bounds meanwhile).  SAGE_POOL_FACTOR=0 starts with the minimum."""
+    from oracle import sage_oracle as orc
+    from sage_amd import synth
+    from sage_amd.parallel import pack_lines, segment_line_bounds
+    monkeypatch.setenv("SAGE_POOL_FACTOR", "0")
+    vocab = [bytes([i]) for i in range(256)] + [b"abcdefghijklmnop", b"qrstuvwxyzABCDEFGHIJ", b"ab", b"the ", b" cat",
+                                               b"pq", b"opq", b"mnopq"]
+    lines = [b"abcdefghijklmnop the cat abcdefghijklmnopq\n", b"qrstuvwxyzABCDEFGHIJ\n", b"x abcdefghijklmnop",
+             b"the qrstuvwxyzABCDEFGHIJ the abcdefghijklmnop cat\n", b"abcdefghijklmnopqrstuvwxyzABCDEFGHIJ the \n"] * 60
+    emb = synth.make_embeddings(len(vocab), 50, seed=2)
+    tok = orc.OracleTokenizer(vocab, 20)
+    occs = {}
+    losses, tt, ttr, sizes = orc.run_shard(tok, lines, emb, flush=50, occurrences=occs)
+    pooled_ids = sum((k + 4) * n for k, n in sizes.items() if k > 11)
+    assert pooled_ids > 1024 + 64, pooled_ids      # more than the minimum pool holds
+    eng = _engine()
+    eng.set_vocab(vocab, None, 20)
+    flat, off = pack_lines(lines)
+    eng.set_corpus(flat, off)
+    eng.set_embeddings(emb)
+    _check_step(eng, segment_line_bounds(len(lines), 1, flush=50), tt, ttr, losses, sizes, want_occ=occs)
+    eng.close()
