@@ -132,6 +132,20 @@ int sage_set_count_mode(sage_ctx* ctx, int mode);
  * that more than 30 % of the occurrences touch such a row, the float64 matrix is used for everything.  1: float64 storage only.  Takes effect at the next sage_set_embeddings. */
 int sage_set_score_mode(sage_ctx* ctx, int mode);
 
+/* word2vec retraining on the GPU.  Replaces the host call
+ *   gensim.models.Word2Vec(corpus_file=..., vector_size=D, negative=N, alpha=ALPHA, window=window_size,
+ *                          min_count=min_count, sg=1, workers=workers)        (embeddings.py:68-75)
+ * and the tokenization loop that feeds it (embeddings.py:61-65): skip-gram with negative sampling over the resident
+ * corpus tokenized with the resident vocabulary, gensim 4.3.2's published algorithm (subsampling `sample`, reduced
+ * windows, unigram^0.75 negatives, linear learning-rate decay over `epochs`; gensim's defaults are min_alpha=1e-4,
+ * epochs=5, sample=1e-3).  out_vectors[id*dim + d] receives the float32 input vectors widened to float64 (what
+ * model.wv[token] holds) and out_counts[id] the token count of id in the tokenized corpus; ids whose count is below
+ * min_count are not trained and the caller gives them the uniform row of embeddings.py:86.  Lock-free training, like
+ * gensim's with workers > 1: results are not reproducible bit for bit (parity unpinned). */
+int sage_train_embeddings(sage_ctx* ctx, int32_t dim, int32_t window, int32_t negative, double alpha, double min_alpha,
+                          int32_t epochs, double sample, int32_t min_count, uint64_t seed, int64_t vsize,
+                          double* out_vectors /*[vsize*dim]*/, int64_t* out_counts /*[vsize]*/);
+
 /* Workload statistics of the last step, for the roofline's algorithmic bytes:
  * out[0]=tokens, out[1]=corpus bytes, out[2]=ablated occurrences, out[3]=embedding rows touched,
  * out[4]=signed pair records, out[5]=distinct-count probes inserted, out[6]=bytes per stored embedding element on

@@ -71,6 +71,9 @@ def load():
     lib.sage_set_score_mode.argtypes = [vp, C.c_int]
     lib.sage_set_count_mode.restype = C.c_int
     lib.sage_set_count_mode.argtypes = [vp, C.c_int]
+    lib.sage_train_embeddings.restype = C.c_int
+    lib.sage_train_embeddings.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_double,
+                                          C.c_int32, C.c_uint64, C.c_int64, C.POINTER(C.c_double), pi64]
     lib.sage_get_step_stats.restype = C.c_int
     lib.sage_get_step_stats.argtypes = [vp, pi64]
     _lib = lib
@@ -80,7 +83,7 @@ def load():
 EXPORTED = ["sage_version", "sage_create", "sage_destroy", "sage_last_error", "sage_set_vocab", "sage_set_corpus",
             "sage_set_embeddings", "sage_tokenize", "sage_ablation_step", "sage_ablation_step_device",
             "sage_set_profiling", "sage_reset_kernel_times", "sage_get_kernel_times", "sage_set_batch_bytes",
-            "sage_set_match_mode", "sage_set_count_mode", "sage_set_score_mode", "sage_get_step_stats"]
+            "sage_set_match_mode", "sage_set_count_mode", "sage_set_score_mode", "sage_train_embeddings", "sage_get_step_stats"]
 
 
 class HipSage:
@@ -208,6 +211,16 @@ class HipSage:
     def set_score_mode(self, mode: int):
         """0 = float32 row storage where lossless (default), 1 = float64 storage; call before set_embeddings."""
         self._check(self._lib.sage_set_score_mode(self._h, int(mode)))
+
+    def train_embeddings(self, vsize: int, dim: int, window: int = 5, negative: int = 15, alpha: float = 0.025,
+                         min_alpha: float = 1e-4, epochs: int = 5, sample: float = 1e-3, min_count: int = 1, seed: int = 1):
+        """-> (vectors float64 [vsize, dim], counts int64 [vsize]); see sage_train_embeddings in include/sage_hip.h."""
+        vec = np.zeros((int(vsize), int(dim)), dtype=np.float64)
+        counts = np.zeros(int(vsize), dtype=np.int64)
+        self._check(self._lib.sage_train_embeddings(self._h, int(dim), int(window), int(negative), float(alpha), float(min_alpha),
+                                                    int(epochs), float(sample), int(min_count), int(seed) & (2 ** 64 - 1),
+                                                    int(vsize), _ptr(vec, C.c_double), _ptr(counts, C.c_int64)))
+        return vec, counts
 
     def step_stats(self):
         out = np.zeros(8, dtype=np.int64)

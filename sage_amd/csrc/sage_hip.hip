@@ -2,11 +2,13 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/sage_hip.h"
@@ -14,6 +16,7 @@
 #include "sage_kernels.h"
 #include "sage_kernels2.h"
 #include "sage_kernels3.h"
+#include "sage_w2v.h"
 
 #define SAGE_VERSION_STR "0.1.0"
 
@@ -55,6 +58,7 @@ struct sage_ctx {
     DevBuf emb32;         // float32 rows, when most rows are float32-representable (word2vec output is)
     DevBuf inexact;       // bitmap of the rows that are not: their pairs are recomputed from `emb`
     DevBuf inex_list, inex_count;
+    DevBuf w2v_counts, w2v_keep, w2v_dropped, w2v_aprob, w2v_aidx, w2v_syn0, w2v_syn1;   // sage_train_embeddings
     DevBuf long_list, long_count;   // occurrences whose window does not fit the inline descriptor (k_describe<true>)
     int64_t emb_rows = 0, n_inexact = 0;
     int dim = 0, dp = 0;
@@ -578,7 +582,7 @@ void sage_destroy(sage_ctx* c) {
     DevBuf* all[] = {&c->buckets, &c->keys, &c->byte_id, &c->bloom, &c->corpus, &c->rem, &c->line_off, &c->emb, &c->M, &c->ntok,
                      &c->tokoff, &c->tile_sums, &c->grand_total, &c->tok_w0, &c->occ_pos, &c->set, &c->seg_line_rel,
                      &c->seg_tok_off, &c->set_base, &c->set_mask, &c->seg_pairs, &c->desc, &c->gcache, &c->hist1, &c->bucket_off, &c->rec_a, &c->rec_b, &c->nocc, &c->occoff, &c->occ_tok,
-                     &c->np_ab, &c->dot_off, &c->dots, &c->pool, &c->pool_cursor, &c->emb32, &c->inexact, &c->inex_list, &c->inex_count, &c->long_list, &c->long_count, &c->ex_ids, &c->ex_starts, &c->ex_widths, &c->loss,
+                     &c->np_ab, &c->dot_off, &c->dots, &c->pool, &c->pool_cursor, &c->emb32, &c->inexact, &c->inex_list, &c->inex_count, &c->long_list, &c->long_count, &c->w2v_counts, &c->w2v_keep, &c->w2v_dropped, &c->w2v_aprob, &c->w2v_aidx, &c->w2v_syn0, &c->w2v_syn1, &c->ex_ids, &c->ex_starts, &c->ex_widths, &c->loss,
                      &c->occ, &c->hist, &c->stats, &c->flags};
     for (DevBuf* b : all) release(*b);
     (void)hipStreamDestroy(c->stream);
@@ -729,6 +733,160 @@ int sage_set_embeddings(sage_ctx* c, const double* emb, int64_t rows, int32_t di
         HIP_TRY(c, hipMemcpy(c->inexact.p, bitmap.data(), bitmap.size() * 4, hipMemcpyHostToDevice));
     }
     c->have_emb = true;
+    return SAGE_OK;
+}
+
+// tokens of the lines [l0, l1) as the compact arrays of a step (tok_w0, line token offsets): matcher + base walk
+static int w2v_tokenize_batch(sage_ctx* c, int64_t l0, int64_t l1, uint32_t* n_tok_out) {
+    int rc;
+    if ((rc = match_and_count(c, l0, l1, nullptr))) return rc;
+    uint64_t gt[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(gt, c->grand_total.p, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (gt[0] >= 0xFFFFFF00ull) return fail(c, SAGE_E_LIMIT, "a batch must stay under 2^32 tokens");
+    const uint32_t n_tok = (uint32_t)gt[0], n_occ = (uint32_t)gt[1], nl = (uint32_t)(l1 - l0);
+    *n_tok_out = n_tok;
+    if (n_tok == 0) return SAGE_OK;
+    if ((rc = ensure(c, c->tok_w0, (size_t)n_tok * 4))) return rc;
+    if ((rc = ensure(c, c->occ_pos, (size_t)std::max(n_occ, 1u) * 4))) return rc;
+    if ((rc = ensure(c, c->occ_tok, (size_t)std::max(n_occ, 1u) * 4))) return rc;
+    k_walk_write<false><<<cdiv(nl, 256), 256, 0, c->stream>>>(
+        c->line_off.as<int64_t>(), l0, nl, c->h_line_off[l0], c->M.as<uint2>(), c->tokoff.as<uint32_t>(),
+        c->occoff.as<uint32_t>(), c->tok_w0.as<uint32_t>(), c->occ_pos.as<uint32_t>(), c->occ_tok.as<uint32_t>(),
+        nullptr, nullptr, nullptr);
+    HIP_TRY(c, hipGetLastError());
+    return SAGE_OK;
+}
+
+int sage_train_embeddings(sage_ctx* c, int32_t dim, int32_t window, int32_t negative, double alpha, double min_alpha,
+                          int32_t epochs, double sample, int32_t min_count, uint64_t seed, int64_t vsize,
+                          double* out_vectors, int64_t* out_counts) {
+    int rc;
+    if ((rc = check_ready(c, false))) return rc;
+    if (!out_vectors || !out_counts || dim <= 0 || window < 1 || window > 31 || negative < 1 || negative > 31 || epochs < 1 ||
+        !(alpha > 0) || min_alpha < 0 || sample < 0 || min_count < 1)
+        return fail(c, SAGE_E_ARG, "bad argument (1 <= window, negative <= 31)");
+    if (dim > 512) return fail(c, SAGE_E_LIMIT, "embedding dimension above 512 is not supported");
+    if (vsize <= c->max_id) return fail(c, SAGE_E_ARG, "vsize must exceed the largest token id");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const int dp = padded_dim(dim);
+    const size_t V = (size_t)vsize;
+
+    // batches of lines
+    std::vector<std::pair<int64_t, int64_t>> batches;
+    for (int64_t l0 = 0; l0 < c->n_lines;) {
+        int64_t l1 = l0 + 1;
+        while (l1 < c->n_lines && c->h_line_off[l1 + 1] - c->h_line_off[l0] <= c->batch_bytes) ++l1;
+        batches.emplace_back(l0, l1);
+        l0 = l1;
+    }
+    // ---- pass 1: token counts (the vocabulary scan of word2vec)
+    if ((rc = ensure(c, c->w2v_counts, V * 8))) return rc;
+    HIP_TRY(c, hipMemsetAsync(c->w2v_counts.p, 0, V * 8, c->stream));
+    uint64_t total_tokens = 0;
+    for (auto& b : batches) {
+        uint32_t n_tok = 0;
+        if ((rc = w2v_tokenize_batch(c, b.first, b.second, &n_tok))) return rc;
+        total_tokens += n_tok;
+        if (n_tok)
+            k_token_hist<<<std::min<uint32_t>(cdiv(n_tok, 256), 256u * 8u), 256, 0, c->stream>>>(
+                c->tok_w0.as<uint32_t>(), n_tok, c->w2v_counts.as<unsigned long long>());
+    }
+    std::vector<uint64_t> counts(V);
+    HIP_TRY(c, hipMemcpyAsync(counts.data(), c->w2v_counts.p, V * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < V; ++i) out_counts[i] = (int64_t)counts[i];
+
+    // ---- sampling tables
+    double retained = 0;
+    for (size_t i = 0; i < V; ++i) if (counts[i] >= (uint64_t)min_count) retained += (double)counts[i];
+    std::vector<uint32_t> keep(V, 0);
+    std::vector<uint8_t> dropped(V, 1);
+    std::vector<double> w(V, 0.0);
+    double wsum = 0;
+    const double thr = sample * retained;   // gensim: threshold_count = sample * retain_total
+    for (size_t i = 0; i < V; ++i) {
+        if (counts[i] < (uint64_t)min_count || counts[i] == 0) continue;
+        dropped[i] = 0;
+        const double v = (double)counts[i];
+        double p = (sample > 0 && thr > 0) ? (std::sqrt(v / thr) + 1.0) * (thr / v) : 1.0;
+        if (p > 1.0) p = 1.0;
+        keep[i] = (uint32_t)std::min(4294967295.0, std::floor(p * 4294967296.0));
+        w[i] = std::pow(v, 0.75);           // ns_exponent
+        wsum += w[i];
+    }
+    // alias table (Vose) of w / wsum over all V slots (zero-weight slots always redirect)
+    std::vector<float> aprob(V, 0.0f);
+    std::vector<uint32_t> aidx(V, 0);
+    {
+        std::vector<double> q(V);
+        std::vector<uint32_t> small, large;
+        for (size_t i = 0; i < V; ++i) {
+            q[i] = wsum > 0 ? w[i] / wsum * (double)V : 1.0;
+            (q[i] < 1.0 ? small : large).push_back((uint32_t)i);
+        }
+        while (!small.empty() && !large.empty()) {
+            const uint32_t s_ = small.back(), l_ = large.back();
+            small.pop_back();
+            aprob[s_] = (float)q[s_]; aidx[s_] = l_;
+            q[l_] = (q[l_] + q[s_]) - 1.0;
+            if (q[l_] < 1.0) { large.pop_back(); small.push_back(l_); }
+        }
+        for (uint32_t i : large) { aprob[i] = 1.0f; aidx[i] = i; }
+        for (uint32_t i : small) { aprob[i] = 1.0f; aidx[i] = i; }   // numerical leftovers
+    }
+    // ---- initial vectors: syn0 ~ U(-1,1)/dim (gensim 4 prep_vectors), syn1neg = 0
+    std::vector<float> syn0(V * (size_t)dp, 0.0f);
+    {
+        uint64_t st = seed ^ 0x5851F42D4C957F2Dull;
+        for (size_t r = 0; r < V; ++r)
+            for (int d = 0; d < dim; ++d) {
+                st += 0x9E3779B97F4A7C15ull;
+                const uint64_t z = sage_mix64(st);
+                syn0[r * dp + d] = (float)((((double)(z >> 11) * (1.0 / 9007199254740992.0)) * 2.0 - 1.0) / dim);
+            }
+    }
+    if ((rc = ensure(c, c->w2v_keep, V * 4))) return rc;
+    if ((rc = ensure(c, c->w2v_dropped, V))) return rc;
+    if ((rc = ensure(c, c->w2v_aprob, V * 4))) return rc;
+    if ((rc = ensure(c, c->w2v_aidx, V * 4))) return rc;
+    if ((rc = ensure(c, c->w2v_syn0, syn0.size() * 4))) return rc;
+    if ((rc = ensure(c, c->w2v_syn1, syn0.size() * 4))) return rc;
+    HIP_TRY(c, hipMemcpy(c->w2v_keep.p, keep.data(), V * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->w2v_dropped.p, dropped.data(), V, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->w2v_aprob.p, aprob.data(), V * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->w2v_aidx.p, aidx.data(), V * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->w2v_syn0.p, syn0.data(), syn0.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemset(c->w2v_syn1.p, 0, syn0.size() * 4));
+
+    // ---- training
+    for (int32_t ep = 0; ep < epochs && total_tokens > 0; ++ep) {
+        uint64_t before = 0;
+        for (auto& b : batches) {
+            uint32_t n_tok = 0;
+            if ((rc = w2v_tokenize_batch(c, b.first, b.second, &n_tok))) return rc;
+            if (!n_tok) continue;
+            W2VArgs a{c->tok_w0.as<uint32_t>(), c->tokoff.as<uint32_t>(), (uint32_t)(b.second - b.first), before, total_tokens,
+                      c->w2v_keep.as<uint32_t>(), c->w2v_dropped.as<uint8_t>(), c->w2v_aprob.as<float>(), c->w2v_aidx.as<uint32_t>(),
+                      (uint32_t)V, c->w2v_syn0.as<float>(), c->w2v_syn1.as<float>(), (uint32_t)dp, (uint32_t)window,
+                      (uint32_t)negative, (uint32_t)ep, (uint32_t)epochs, (float)alpha, (float)min_alpha, seed};
+            const uint32_t grid = std::min<uint32_t>(cdiv(a.n_lines, 256 / W2V_G), (uint32_t)c->n_cu * 8u);
+            switch (dp / W2V_G) {
+            case 2: k_w2v_train<2><<<grid, 256, 0, c->stream>>>(a); break;
+            case 4: k_w2v_train<4><<<grid, 256, 0, c->stream>>>(a); break;
+            case 8: k_w2v_train<8><<<grid, 256, 0, c->stream>>>(a); break;
+            case 16: k_w2v_train<16><<<grid, 256, 0, c->stream>>>(a); break;
+            case 24: k_w2v_train<24><<<grid, 256, 0, c->stream>>>(a); break;
+            default: k_w2v_train<32><<<grid, 256, 0, c->stream>>>(a); break;
+            }
+            HIP_TRY(c, hipGetLastError());
+            before += n_tok;
+        }
+    }
+    HIP_TRY(c, hipMemcpyAsync(syn0.data(), c->w2v_syn0.p, syn0.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (size_t r = 0; r < V; ++r)
+        for (int d = 0; d < dim; ++d) out_vectors[r * dim + d] = (double)syn0[r * dp + d];
     return SAGE_OK;
 }
 

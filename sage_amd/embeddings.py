@@ -1,12 +1,17 @@
-"""Embedding checkpoints and (host-side) word2vec retraining (reference: embeddings.py:28-89).
+"""Embedding checkpoints and word2vec retraining (reference: embeddings.py:28-89).
 
-gensim stays on the host (north star) and is imported only when a retrain is really needed: a run whose
-`embeddings_<label>.npy` files are present never touches it -- that is also the reference's resume mechanism
-(embeddings.py:31-35).  The corpus file handed to gensim is written from GPU tokenization (one batched call,
-model.py:103-107 semantics) instead of a per-line Python loop (embeddings.py:61-65)."""
+A run whose `embeddings_<label>.npy` files are present never retrains -- that is also the reference's resume
+mechanism (embeddings.py:31-35).  When a retrain is needed there are two back ends:
+  "gensim"  the reference's host call (embeddings.py:68-75); the corpus file handed to gensim is written from GPU
+            tokenization (one batched call, model.py:103-107 semantics) instead of a per-line Python loop;
+  "hip"     `sage_train_embeddings` (include/sage_hip.h): the same skip-gram / negative-sampling algorithm on the GPU
+            over the resident corpus, no corpus file and no gensim needed.
+SAGE_W2V_BACKEND=gensim|hip chooses; the default is gensim when it can be imported (the reference's behaviour), else
+hip.  Neither back end is reproducible bit for bit (lock-free training): parity of the vectors is unpinned."""
 from __future__ import annotations
 
 import logging
+import os
 import time
 from pathlib import Path
 from typing import List
@@ -48,7 +53,62 @@ def write_gensim_corpus(sage_model, partial_corpus, out_path: Path, lines_per_ca
                 at += n
 
 
+GENSIM_EPOCHS = 5          # gensim.models.Word2Vec defaults the reference relies on (embeddings.py:68-75 passes none)
+GENSIM_SAMPLE = 1e-3
+GENSIM_MIN_ALPHA = 1e-4
+
+
+def _backend() -> str:
+    want = os.environ.get("SAGE_W2V_BACKEND", "").strip().lower()
+    if want in ("gensim", "hip"):
+        return want
+    try:
+        import gensim.models  # noqa: F401
+        return "gensim"
+    except ImportError:
+        return "hip"
+
+
+def fill_matrix(sage_model, D: int, vector_of) -> np.ndarray:
+    """embeddings.py:77-89: one row per vocabulary id, in id order; `vector_of(idx, token)` returns the trained vector
+    or None, and a missing vector gets the uniform draw from numpy's global RNG, in the same order as the reference."""
+    emb = np.zeros(shape=(sage_model.vocab_size(), D))
+    half = 0.5 / D
+    for idx, token in sage_model.inv_str_vocab.items():
+        v = vector_of(idx, token)
+        if v is not None:
+            emb[idx] = v
+        else:
+            emb[idx] = np.random.uniform(low=-half, high=half, size=(1, D))
+    return emb
+
+
+def train_embeddings_hip(sage_model, partial_corpus, word2vec_params: Word2VecParams, seed: int = 1) -> np.ndarray:
+    """word2vec on the GPU over the resident corpus (sage_train_embeddings)."""
+    from .parallel import _state, get_engine, sync_corpus, sync_vocab
+    if not word2vec_params.sg:
+        raise ValueError("the HIP word2vec back end implements skip-gram (sg=1), the reference's setting")
+    engine = get_engine()
+    slot = _state[engine.device]
+    sync_vocab(engine, sage_model, slot)
+    sync_corpus(engine, partial_corpus, slot)
+    vsize = max(sage_model.byte_vocab.values()) + 1
+    vec, counts = engine.train_embeddings(vsize, word2vec_params.D, window=word2vec_params.window_size,
+                                          negative=word2vec_params.N, alpha=word2vec_params.ALPHA,
+                                          min_alpha=GENSIM_MIN_ALPHA, epochs=GENSIM_EPOCHS, sample=GENSIM_SAMPLE,
+                                          min_count=word2vec_params.min_count, seed=seed)
+    trained = counts >= word2vec_params.min_count
+    return fill_matrix(sage_model, word2vec_params.D, lambda idx, token: vec[idx] if trained[idx] else None)
+
+
 def train_embeddings(sage_model, partial_corpus: List[str], workers: int, word2vec_params: Word2VecParams) -> np.ndarray:
+    if _backend() == "hip":
+        logging.info("word2vec back end: HIP (sage_train_embeddings)")
+        return train_embeddings_hip(sage_model, partial_corpus, word2vec_params)
+    return train_embeddings_gensim(sage_model, partial_corpus, workers, word2vec_params)
+
+
+def train_embeddings_gensim(sage_model, partial_corpus: List[str], workers: int, word2vec_params: Word2VecParams) -> np.ndarray:
     try:
         import gensim.models  # pinned 4.3.2 by the reference (pyproject.toml:8-11); host-side only
     except ImportError as exc:
@@ -66,12 +126,5 @@ def train_embeddings(sage_model, partial_corpus: List[str], workers: int, word2v
                                  negative=word2vec_params.N, alpha=word2vec_params.ALPHA,
                                  window=word2vec_params.window_size, min_count=word2vec_params.min_count,
                                  sg=word2vec_params.sg, workers=workers)
-    emb = np.zeros(shape=(sage_model.vocab_size(), word2vec_params.D))
     known = w2v.wv.key_to_index
-    half = 0.5 / word2vec_params.D
-    for idx, token in sage_model.inv_str_vocab.items():
-        if token in known:
-            emb[idx] = w2v.wv[token]
-        else:  # below min_count: same random fallback, same RNG stream order as embeddings.py:86
-            emb[idx] = np.random.uniform(low=-half, high=half, size=(1, word2vec_params.D))
-    return emb
+    return fill_matrix(sage_model, word2vec_params.D, lambda idx, token: w2v.wv[token] if token in known else None)
