@@ -67,9 +67,10 @@ struct sage_ctx {
     int score_mode = 0;   // 0 = float32 storage when lossless for most rows, 1 = always float64 storage
 
     // scratch (grow-only; nothing is allocated in the steady state)
-    DevBuf M, ntok, tokoff, tile_sums, grand_total, tok_w0, occ_pos, set, seg_line_rel, seg_tok_off, set_base, set_mask, seg_pairs, desc, gcache, hist1, bucket_off, rec_a, rec_b,
+    DevBuf M, ntok, tokoff, tile_sums, grand_total, tok_w0, occ_pos, set, seg_line_rel, seg_tok_off, set_base, set_mask, seg_pairs, desc, gcache, hist1, bucket_off, bucket_lim, rec_a, rec_b,
         nocc, occoff, occ_tok, np_ab, dot_off, dots, pool, pool_cursor;
     int pool_factor = 8;  // id-pool words per occurrence (grown on overflow)
+    bool exact_buckets = false;   // v2 count: size the key buckets with a counting pass instead of the estimate
     int count_mode = 0;  // 0 = partition + LDS dedupe (v2), 1 = per-segment HBM sets (v1, also the overflow fallback)
     DevBuf ex_ids, ex_starts, ex_widths;
     DevBuf loss, occ, hist, stats, flags;
@@ -438,39 +439,63 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
                 const size_t nbk = (size_t)nsb * NB1;
                 if ((rc = ensure(c, c->hist1, nbk * 8))) return rc;
                 if ((rc = ensure(c, c->bucket_off, (nbk + 1) * 8))) return rc;
-                HIP_TRY(c, hipMemsetAsync(c->hist1.p, 0, nbk * 8, c->stream));
-                {
-                    Prof p(c, SAGE_K_COUNT);
-                    k_key_partition<0><<<pgrid, PART_TILE, 0, c->stream>>>(c->desc.as<uint4>(), c->pool.as<uint32_t>(),
-                                                                     c->occ_tok.as<uint32_t>(), A.tok_w0, n_occ, S,
-                                                                     c->hist1.as<unsigned long long>(), nullptr);
-                    k_key_partition_long<0><<<lgrid, 256, 0, c->stream>>>(
-                        c->desc.as<uint4>(), c->pool.as<uint32_t>(), c->occ_tok.as<uint32_t>(), A.tok_w0,
-                        c->long_list.as<uint32_t>(), c->long_count.as<uint32_t>(), S, c->hist1.as<unsigned long long>(), nullptr);
-                }
-                std::vector<uint64_t> h1(nbk), boff(nbk + 1);
-                HIP_TRY(c, hipMemcpyAsync(h1.data(), c->hist1.p, nbk * 8, hipMemcpyDeviceToHost, c->stream));
-                HIP_TRY(c, hipMemcpyAsync(&n_dots, c->grand_total.as<uint64_t>() + 1, 8, hipMemcpyDeviceToHost, c->stream));
-                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                if ((rc = ensure(c, c->bucket_lim, nbk * 8))) return rc;
+                std::vector<uint64_t> boff(nbk + 1), blim(nbk);
                 uint64_t total = 0;
-                for (size_t i = 0; i < nbk; ++i) { boff[i] = total; total += h1[i]; }
+                if (c->exact_buckets) {
+                    // counting pass: exact bucket sizes
+                    HIP_TRY(c, hipMemsetAsync(c->hist1.p, 0, nbk * 8, c->stream));
+                    {
+                        Prof p(c, SAGE_K_COUNT);
+                        k_key_partition<0><<<pgrid, PART_TILE, 0, c->stream>>>(c->desc.as<uint4>(), c->pool.as<uint32_t>(),
+                                                                         c->occ_tok.as<uint32_t>(), A.tok_w0, n_occ, S,
+                                                                         c->hist1.as<unsigned long long>(), nullptr, nullptr,
+                                                                         c->flags.as<uint32_t>());
+                        k_key_partition_long<0><<<lgrid, 256, 0, c->stream>>>(
+                            c->desc.as<uint4>(), c->pool.as<uint32_t>(), c->occ_tok.as<uint32_t>(), A.tok_w0,
+                            c->long_list.as<uint32_t>(), c->long_count.as<uint32_t>(), S, c->hist1.as<unsigned long long>(),
+                            nullptr, nullptr, c->flags.as<uint32_t>());
+                    }
+                    std::vector<uint64_t> h1(nbk);
+                    HIP_TRY(c, hipMemcpyAsync(h1.data(), c->hist1.p, nbk * 8, hipMemcpyDeviceToHost, c->stream));
+                    HIP_TRY(c, hipMemcpyAsync(&n_dots, c->grand_total.as<uint64_t>() + 1, 8, hipMemcpyDeviceToHost, c->stream));
+                    HIP_TRY(c, hipStreamSynchronize(c->stream));
+                    for (size_t i = 0; i < nbk; ++i) { boff[i] = total; total += h1[i]; blim[i] = total; }
+                } else {
+                    // no counting pass: the hash spreads a segment's pairs evenly over its 64 buckets, so each region is
+                    // sized from the segment's exact pair count (k_describe) plus slack for repeated keys; a bucket
+                    // that still overflows makes the step redo itself with the counting pass
+                    std::vector<uint64_t> spairs(nsb);
+                    HIP_TRY(c, hipMemcpyAsync(spairs.data(), c->seg_pairs.p, (size_t)nsb * 8, hipMemcpyDeviceToHost, c->stream));
+                    HIP_TRY(c, hipMemcpyAsync(&n_dots, c->grand_total.as<uint64_t>() + 1, 8, hipMemcpyDeviceToHost, c->stream));
+                    HIP_TRY(c, hipStreamSynchronize(c->stream));
+                    for (uint32_t s2 = 0; s2 < nsb; ++s2) {
+                        const uint64_t cap = spairs[s2] / NB1 + spairs[s2] / (NB1 * 12) + std::min<uint64_t>(4096, spairs[s2]);
+                        for (uint32_t b2 = 0; b2 < NB1; ++b2) {
+                            boff[(size_t)s2 * NB1 + b2] = total; total += cap; blim[(size_t)s2 * NB1 + b2] = total;
+                        }
+                    }
+                }
                 boff[nbk] = total;
                 if ((rc = ensure(c, c->rec_a, std::max<uint64_t>(total, 1) * 8))) return rc;
                 if ((rc = ensure(c, c->rec_b, std::max<uint64_t>(total, 1) * 8))) return rc;
                 HIP_TRY(c, hipMemcpyAsync(c->bucket_off.p, boff.data(), (nbk + 1) * 8, hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(c, hipMemcpyAsync(c->bucket_lim.p, blim.data(), nbk * 8, hipMemcpyHostToDevice, c->stream));
                 HIP_TRY(c, hipMemcpyAsync(c->hist1.p, boff.data(), nbk * 8, hipMemcpyHostToDevice, c->stream));  // cursors
                 {
                     Prof p(c, SAGE_K_COUNT);
                     k_key_partition<1><<<pgrid, PART_TILE, 0, c->stream>>>(c->desc.as<uint4>(), c->pool.as<uint32_t>(),
                                                                      c->occ_tok.as<uint32_t>(), A.tok_w0, n_occ, S,
                                                                      c->hist1.as<unsigned long long>(),
-                                                                     c->rec_a.as<unsigned long long>());
+                                                                     c->rec_a.as<unsigned long long>(),
+                                                                     c->bucket_lim.as<unsigned long long>(), c->flags.as<uint32_t>());
                     k_key_partition_long<1><<<lgrid, 256, 0, c->stream>>>(
                         c->desc.as<uint4>(), c->pool.as<uint32_t>(), c->occ_tok.as<uint32_t>(), A.tok_w0,
                         c->long_list.as<uint32_t>(), c->long_count.as<uint32_t>(), S, c->hist1.as<unsigned long long>(),
-                        c->rec_a.as<unsigned long long>());
+                        c->rec_a.as<unsigned long long>(), c->bucket_lim.as<unsigned long long>(), c->flags.as<uint32_t>());
                     const uint32_t dgrid = (uint32_t)std::min<size_t>(nbk, 256u * 4u);
-                    k_key_dedupe<<<dgrid, 256, 0, c->stream>>>(c->bucket_off.as<unsigned long long>(), (uint32_t)nbk,
+                    k_key_dedupe<<<dgrid, 256, 0, c->stream>>>(c->bucket_off.as<unsigned long long>(),
+                                                               c->hist1.as<unsigned long long>(), (uint32_t)nbk,
                                                                c->rec_a.as<unsigned long long>(),
                                                                c->rec_b.as<unsigned long long>(),
                                                                c->stats.as<unsigned long long>(), c->flags.as<uint32_t>());
@@ -518,6 +543,11 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
         if (flags[FLAG_POOL_FULL]) {
             if (attempt >= 6) return fail(c, SAGE_E_LIMIT, "window-id pool overflowed");
             c->pool_factor = std::max(1, c->pool_factor) * 4;   // long ablation chains: redo the step with a larger id pool
+            continue;
+        }
+        if (flags[FLAG_BUCKET_OVERFLOW]) {
+            if (c->exact_buckets) return fail(c, SAGE_E_LIMIT, "a key bucket overflowed its exact size");
+            c->exact_buckets = true;   // heavily repeated keys: redo the step with the counting pass
             continue;
         }
         if (flags[FLAG_SET_OVERFLOW]) {
@@ -581,7 +611,7 @@ void sage_destroy(sage_ctx* c) {
     for (auto e : c->ev_free) (void)hipEventDestroy(e);
     DevBuf* all[] = {&c->buckets, &c->keys, &c->byte_id, &c->bloom, &c->corpus, &c->rem, &c->line_off, &c->emb, &c->M, &c->ntok,
                      &c->tokoff, &c->tile_sums, &c->grand_total, &c->tok_w0, &c->occ_pos, &c->set, &c->seg_line_rel,
-                     &c->seg_tok_off, &c->set_base, &c->set_mask, &c->seg_pairs, &c->desc, &c->gcache, &c->hist1, &c->bucket_off, &c->rec_a, &c->rec_b, &c->nocc, &c->occoff, &c->occ_tok,
+                     &c->seg_tok_off, &c->set_base, &c->set_mask, &c->seg_pairs, &c->desc, &c->gcache, &c->hist1, &c->bucket_off, &c->bucket_lim, &c->rec_a, &c->rec_b, &c->nocc, &c->occoff, &c->occ_tok,
                      &c->np_ab, &c->dot_off, &c->dots, &c->pool, &c->pool_cursor, &c->emb32, &c->inexact, &c->inex_list, &c->inex_count, &c->long_list, &c->long_count, &c->w2v_counts, &c->w2v_keep, &c->w2v_dropped, &c->w2v_aprob, &c->w2v_aidx, &c->w2v_syn0, &c->w2v_syn1, &c->ex_ids, &c->ex_starts, &c->ex_widths, &c->loss,
                      &c->occ, &c->hist, &c->stats, &c->flags};
     for (DevBuf* b : all) release(*b);

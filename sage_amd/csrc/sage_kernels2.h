@@ -10,7 +10,7 @@
 #define DESC_LDS_STRIDE 17  // 16 words + 1 pad: conflict-free per-thread row writes
 #define SEG_LDS 128         // count segments of a batch whose pair totals k_describe accumulates in LDS
 #define DESC_SPAN 3072      // corpus positions of the match table one k_describe tile stages in LDS
-enum { FLAG_POOL_FULL = 3 };
+enum { FLAG_POOL_FULL = 3, FLAG_BUCKET_OVERFLOW = 4 };
 
 // ----------------------------------------------------------------------------------------------------------
 // Per-block accumulation cache in LDS for the vocabulary-sized result vectors.  Token frequencies are Zipfian: a few

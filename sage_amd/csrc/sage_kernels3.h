@@ -105,7 +105,10 @@ __global__ __launch_bounds__(PART_TILE) void k_key_partition(const uint4* __rest
                                                        const uint32_t* __restrict__ occ_tok,
                                                        const uint32_t* __restrict__ tok_w0, uint32_t n_occ, SegPlan S,
                                                        unsigned long long* __restrict__ counters,
-                                                       unsigned long long* __restrict__ rec) {
+                                                       unsigned long long* __restrict__ rec,
+                                                       const unsigned long long* __restrict__ limit, uint32_t* __restrict__ flags) {
+    // limit != nullptr (MODE 1 without a counting pass): bucket regions were sized from an estimate; a reservation that
+    // would run past limit[bucket] raises FLAG_BUCKET_OVERFLOW and writes nothing (the step is redone with exact sizes)
     __shared__ unsigned int cnt[2][NB1];
     __shared__ unsigned long long gbase[2][NB1];
     const uint32_t n_round = (n_occ + PART_TILE - 1u) / PART_TILE * PART_TILE;
@@ -130,7 +133,11 @@ __global__ __launch_bounds__(PART_TILE) void k_key_partition(const uint4* __rest
                 const uint32_t b1 = (uint32_t)sage_mix64(key) & (NB1 - 1);
                 if (local) atomicAdd(&cnt[seg - s0][b1], 1u);
                 else if (MODE == 0) atomicAdd(&counters[(size_t)seg * NB1 + b1], 1ull);
-                else rec[atomicAdd(&counters[(size_t)seg * NB1 + b1], 1ull)] = key;
+                else {
+                    const unsigned long long at = atomicAdd(&counters[(size_t)seg * NB1 + b1], 1ull);
+                    if (!limit || at < limit[(size_t)seg * NB1 + b1]) rec[at] = key;
+                    else flags[FLAG_BUCKET_OVERFLOW] = 1;
+                }
             });
         }
         __syncthreads();
@@ -138,7 +145,8 @@ __global__ __launch_bounds__(PART_TILE) void k_key_partition(const uint4* __rest
             const uint32_t ls = threadIdx.x / NB1, b = threadIdx.x % NB1;
             const uint32_t n = cnt[ls][b];
             if (n && (s0 + ls) < S.n_seg) {
-                const unsigned long long old = atomicAdd(&counters[(size_t)(s0 + ls) * NB1 + b], (unsigned long long)n);
+                unsigned long long old = atomicAdd(&counters[(size_t)(s0 + ls) * NB1 + b], (unsigned long long)n);
+                if (MODE == 1 && limit && old + n > limit[(size_t)(s0 + ls) * NB1 + b]) { flags[FLAG_BUCKET_OVERFLOW] = 1; old = ~0ull; }
                 if (MODE == 1) gbase[ls][b] = old;
             }
             if (MODE == 1) cnt[ls][b] = 0;
@@ -150,7 +158,8 @@ __global__ __launch_bounds__(PART_TILE) void k_key_partition(const uint4* __rest
                     const uint64_t key = make_key(a, lo, hi);
                     const uint32_t b1 = (uint32_t)sage_mix64(key) & (NB1 - 1);
                     const uint32_t r = atomicAdd(&cnt[seg - s0][b1], 1u);
-                    rec[gbase[seg - s0][b1] + r] = key;
+                    const unsigned long long gb = gbase[seg - s0][b1];
+                    if (gb != ~0ull) rec[gb + r] = key;
                 });
             }
         }
@@ -192,7 +201,8 @@ __global__ __launch_bounds__(256) void k_key_partition_long(const uint4* __restr
                                                             const uint32_t* __restrict__ long_list,
                                                             const uint32_t* __restrict__ long_count, SegPlan S,
                                                             unsigned long long* __restrict__ counters,
-                                                            unsigned long long* __restrict__ rec) {
+                                                            unsigned long long* __restrict__ rec,
+                                                            const unsigned long long* __restrict__ limit, uint32_t* __restrict__ flags) {
     static_assert(NB1 == 64, "one lane per coarse bucket");
     __shared__ unsigned int cnt[4][NB1];
     __shared__ unsigned long long gbase[4][NB1];
@@ -229,6 +239,7 @@ __global__ __launch_bounds__(256) void k_key_partition_long(const uint4* __restr
                 const uint32_t nb = cnt[wave][lane];
                 unsigned long long old = 0;
                 if (nb) old = atomicAdd(&counters[(size_t)seg * NB1 + lane], (unsigned long long)nb);
+                if (MODE == 1 && limit && nb && old + nb > limit[(size_t)seg * NB1 + lane]) { flags[FLAG_BUCKET_OVERFLOW] = 1; old = ~0ull; }
                 if (MODE == 1) { gbase[wave][lane] = old; cnt[wave][lane] = 0; }
             }
             if (MODE == 1) {
@@ -241,7 +252,8 @@ __global__ __launch_bounds__(256) void k_key_partition_long(const uint4* __restr
                         const uint64_t key = make_key(a, lo, hi);
                         const uint32_t b1 = (uint32_t)sage_mix64(key) & (NB1 - 1);
                         const uint32_t r = atomicAdd(&cnt[wave][b1], 1u);
-                        rec[gbase[wave][b1] + r] = key;
+                        const unsigned long long gb = gbase[wave][b1];
+                        if (gb != ~0ull) rec[gb + r] = key;
                     });
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -265,7 +277,8 @@ __device__ __forceinline__ uint32_t lds_set_insert(unsigned long long* set, uint
     return 0u;
 }
 
-__global__ __launch_bounds__(256) void k_key_dedupe(const unsigned long long* __restrict__ bucket_off /* n_buckets+1 */,
+__global__ __launch_bounds__(256) void k_key_dedupe(const unsigned long long* __restrict__ bucket_off /* start of every bucket */,
+                                                    const unsigned long long* __restrict__ bucket_end /* cursors after the scatter */,
                                                     uint32_t n_buckets, const unsigned long long* __restrict__ rec_in,
                                                     unsigned long long* __restrict__ rec_tmp,
                                                     unsigned long long* __restrict__ stats, uint32_t* __restrict__ flags) {
@@ -276,7 +289,7 @@ __global__ __launch_bounds__(256) void k_key_dedupe(const unsigned long long* __
     unsigned long long n_distinct = 0;
     for (uint32_t bk = blockIdx.x; bk < n_buckets; bk += gridDim.x) {
         const unsigned long long o0 = bucket_off[bk];
-        const uint32_t cnt = (uint32_t)(bucket_off[bk + 1] - o0);
+        const uint32_t cnt = (uint32_t)min(bucket_end[bk] - o0, bucket_off[bk + 1] - o0);   // (an overflowed bucket is clamped)
         if (cnt == 0) continue;
         const unsigned long long* in = rec_in + o0;
         unsigned long long* tmp = rec_tmp + o0;

@@ -264,3 +264,25 @@ def test_pool_overflow_is_redone(monkeypatch):
     eng.set_embeddings(emb)
     _check_step(eng, segment_line_bounds(len(lines), 1, flush=50), tt, ttr, losses, sizes, want_occ=occs)
     eng.close()
+
+
+def test_repeated_keys_overflow_estimated_buckets():
+    """The key buckets of the distinct count are sized from an estimate (no counting pass); a corpus of identical lines
+    puts tens of thousands of copies of a few keys into single buckets, which must trigger the exact redo, not a
+    wrong count."""
+    from oracle import sage_oracle as orc
+    from sage_amd import synth
+    from sage_amd.parallel import pack_lines, segment_line_bounds
+    vocab = [bytes([i]) for i in range(256)] + [b"the ", b"cat ", b"sat ", b"on ", b"mat", b"th", b"ca", b"sa", b"at "]
+    lines = [b"the cat sat on the mat\n"] * 12000
+    emb = synth.make_embeddings(len(vocab), 50, seed=4)
+    tok = orc.OracleTokenizer(vocab, 16)
+    occs = {}
+    losses, tt, ttr, sizes = orc.run_shard(tok, lines, emb, occurrences=occs)
+    eng = _engine()
+    eng.set_vocab(vocab, None, 16)
+    flat, off = pack_lines(lines)
+    eng.set_corpus(flat, off)
+    eng.set_embeddings(emb)
+    _check_step(eng, segment_line_bounds(len(lines), 1), tt, ttr, losses, sizes, want_occ=occs)
+    eng.close()
