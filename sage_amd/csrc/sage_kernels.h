@@ -364,6 +364,34 @@ __global__ __launch_bounds__(256) void k_walk_count(const int64_t* __restrict__ 
     nocc[l] = mb;   // tokens wider than one byte = ablated occurrences (model.py:170)
 }
 
+// A lane that writes its own run of consecutive 32-bit words gathers four and stores 16 aligned bytes at a time:
+// 4-byte stores from 64 lanes to 64 different lines reach HBM as partial-line writes (8x the bytes, measured).
+struct GroupedWriter {
+    uint32_t* dst;
+    uint32_t first;      // first index this lane writes
+    uint32_t buf[4];
+    __device__ __forceinline__ void init(uint32_t* d, uint32_t f) { dst = d; first = f; buf[0] = buf[1] = buf[2] = buf[3] = 0; }
+    __device__ __forceinline__ void put(uint32_t i, uint32_t v) {
+        const uint32_t k4 = i & 3u;
+        buf[0] = k4 == 0u ? v : buf[0]; buf[1] = k4 == 1u ? v : buf[1];
+        buf[2] = k4 == 2u ? v : buf[2]; buf[3] = k4 == 3u ? v : buf[3];
+        if (k4 == 3u) {
+            if (i - first >= 3u) *reinterpret_cast<uint4*>(dst + (i - 3u)) = make_uint4(buf[0], buf[1], buf[2], buf[3]);
+            else for (uint32_t q = first; q <= i; ++q) dst[q] = pick(q);     // the run's first, partial group
+        }
+    }
+    __device__ __forceinline__ uint32_t pick(uint32_t q) const {
+        const uint32_t k4 = q & 3u;
+        return k4 == 0u ? buf[0] : k4 == 1u ? buf[1] : k4 == 2u ? buf[2] : buf[3];
+    }
+    __device__ __forceinline__ void finish(uint32_t end) {   // end = one past the last index written
+        if ((end & 3u) != 0u && end > first) {
+            const uint32_t g0 = max(end & ~3u, first);
+            for (uint32_t q = g0; q < end; ++q) dst[q] = pick(q);
+        }
+    }
+};
+
 template <bool EXPORT>
 __global__ __launch_bounds__(256) void k_walk_write(const int64_t* __restrict__ line_off, int64_t line0,
                                                     uint32_t n_lines, int64_t pos0, const uint2* __restrict__ M,
@@ -380,6 +408,8 @@ __global__ __launch_bounds__(256) void k_walk_write(const int64_t* __restrict__ 
     uint32_t t = tok_off[l], c = 0;
     const uint32_t nt = tok_off[l + 1] - t;
     uint32_t o = EXPORT ? 0u : occ_off[l];
+    GroupedWriter gw_tok, gw_occ, gw_pos;
+    if (!EXPORT) { gw_tok.init(tok_w0, t); gw_occ.init(occ_tok, o); gw_pos.init(occ_pos, o); }
     while (p < e) {
         const uint32_t m = M[p].x;
         if (EXPORT) {
@@ -388,12 +418,13 @@ __global__ __launch_bounds__(256) void k_walk_write(const int64_t* __restrict__ 
             ex_widths[t] = (int32_t)SAGE_M_LEN(m);
         } else {
             const uint32_t after = nt - 1u - c;
-            tok_w0[t] = SAGE_M_ID(m) | ((c < 3u ? c : 3u) << 20) | ((after < 3u ? after : 3u) << 22);
-            if (SAGE_M_LEN(m) > 1u) { occ_tok[o] = t; occ_pos[o] = p; ++o; }   // compact list of the tokens that get ablated
+            gw_tok.put(t, SAGE_M_ID(m) | ((c < 3u ? c : 3u) << 20) | ((after < 3u ? after : 3u) << 22));
+            if (SAGE_M_LEN(m) > 1u) { gw_occ.put(o, t); gw_pos.put(o, p); ++o; }   // compact list of the tokens that get ablated
         }
         p += SAGE_M_LEN(m);
         ++t; ++c;
     }
+    if (!EXPORT) { gw_tok.finish(t); gw_occ.finish(o); gw_pos.finish(o); }
 }
 
 // ----------------------------------------------------------------------------------------------------------
