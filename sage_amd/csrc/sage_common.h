@@ -39,6 +39,10 @@ SAGE_HD uint32_t sage_slot_want(uint32_t len, uint32_t f) { return (sage_slot_ta
 SAGE_HD uint32_t sage_bloom_word(uint32_t f) { return (f >> 7) & 0x7FFFu; }
 SAGE_HD uint32_t sage_bloom_mask(uint32_t f) { return (1u << (f & 31u)) | (1u << ((f >> 22) & 31u)); }
 
+// Prefix-length table of the matcher: slot = mixed hash of a key's first 4 bytes, value = OR of (1 << (len-1)) over the
+// keys of >= 4 bytes that land there.  Collisions only add bits, so it never rules out a real match.
+#define SAGE_PMASK_SLOTS (1u << 18)
+
 SAGE_HD uint64_t sage_mix64(uint64_t k) {
     k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
     return k;
