@@ -42,6 +42,7 @@ SAGE_HD uint32_t sage_bloom_mask(uint32_t f) { return (1u << (f & 31u)) | (1u <<
 // Prefix-length table of the matcher: slot = mixed hash of a key's first 4 bytes, value = OR of (1 << (len-1)) over the
 // keys of >= 4 bytes that land there.  Collisions only add bits, so it never rules out a real match.
 #define SAGE_PMASK_SLOTS (1u << 18)
+#define SAGE_PMASK8_SLOTS (1u << 17)
 
 SAGE_HD uint64_t sage_mix64(uint64_t k) {
     k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;

@@ -39,7 +39,7 @@ struct sage_ctx {
     std::string err;
 
     // vocabulary
-    DevBuf buckets, keys, byte_id, bloom, pmask;
+    DevBuf buckets, keys, byte_id, bloom, pmask, pmask8;
     int match_mode = 0;  // 0 = LDS-filtered persistent matcher, 1 = plain matcher
     uint32_t bucket_mask = 0, key_plane = 0;
     int max_len = 0;
@@ -184,7 +184,7 @@ int match_and_count(sage_ctx* c, int64_t line0, int64_t line1, uint64_t* out_tot
     if ((rc = ensure(c, c->grand_total, 16))) return rc;
 
     VocabDev v{c->buckets.as<uint4>(), c->bucket_mask, c->keys.as<uint64_t>(), c->key_plane, c->byte_id.as<uint32_t>(),
-               c->bloom.as<uint32_t>(), c->pmask.as<uint32_t>(), c->max_len};
+               c->bloom.as<uint32_t>(), c->pmask.as<uint32_t>(), c->pmask8.as<uint32_t>(), c->max_len};
     if (nb) {
         Prof p(c, SAGE_K_MATCH);
         const uint32_t grid = cdiv(nb, 256);
@@ -609,7 +609,7 @@ void sage_destroy(sage_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     collect_events(c);
     for (auto e : c->ev_free) (void)hipEventDestroy(e);
-    DevBuf* all[] = {&c->buckets, &c->keys, &c->byte_id, &c->bloom, &c->pmask, &c->corpus, &c->rem, &c->line_off, &c->emb, &c->M, &c->ntok,
+    DevBuf* all[] = {&c->buckets, &c->keys, &c->byte_id, &c->bloom, &c->pmask, &c->pmask8, &c->corpus, &c->rem, &c->line_off, &c->emb, &c->M, &c->ntok,
                      &c->tokoff, &c->tile_sums, &c->grand_total, &c->tok_w0, &c->occ_pos, &c->set, &c->seg_line_rel,
                      &c->seg_tok_off, &c->set_base, &c->set_mask, &c->seg_pairs, &c->desc, &c->gcache, &c->hist1, &c->bucket_off, &c->bucket_lim, &c->rec_a, &c->rec_b, &c->nocc, &c->occoff, &c->occ_tok,
                      &c->np_ab, &c->dot_off, &c->dots, &c->pool, &c->pool_cursor, &c->emb32, &c->inexact, &c->inex_list, &c->inex_count, &c->long_list, &c->long_count, &c->w2v_counts, &c->w2v_keep, &c->w2v_dropped, &c->w2v_aprob, &c->w2v_aidx, &c->w2v_syn0, &c->w2v_syn1, &c->ex_ids, &c->ex_starts, &c->ex_widths, &c->loss,
@@ -640,7 +640,7 @@ int sage_set_vocab(sage_ctx* c, const uint8_t* key_bytes, const int64_t* key_off
     const uint64_t nbuckets = pow2ceil(std::max<uint64_t>(16, (uint64_t)n_keys / 2));  // load factor <= 0.5
     std::vector<uint32_t> slots(nbuckets * 4, SAGE_SLOT_EMPTY);
     std::vector<uint32_t> bloom(SAGE_BLOOM_BITS / 32, 0u);
-    std::vector<uint32_t> pmask(SAGE_PMASK_SLOTS, 0u);
+    std::vector<uint32_t> pmask(SAGE_PMASK_SLOTS, 0u), pmask8(SAGE_PMASK8_SLOTS, 0u);
     const uint32_t bmask = (uint32_t)(nbuckets - 1);
     for (int64_t i = 0; i < n_keys; ++i) {
         const uint32_t id = (uint32_t)(key_ids ? key_ids[i] : i);
@@ -656,6 +656,7 @@ int sage_set_vocab(sage_ctx* c, const uint8_t* key_bytes, const int64_t* key_off
         for (uint32_t j = 0; j < len; ++j) {
             h = sage_fnv_step(h, k[j]);
             if (j == 3) pmask[sage_mix32(h) & (SAGE_PMASK_SLOTS - 1u)] |= 1u << (len - 1u);   // len >= 4 here
+            if (j == 7) pmask8[sage_mix32(h) & (SAGE_PMASK8_SLOTS - 1u)] |= 1u << (len - 1u);  // len >= 8 here
         }
         const uint32_t f = sage_mix32(h);
         {
@@ -682,12 +683,14 @@ int sage_set_vocab(sage_ctx* c, const uint8_t* key_bytes, const int64_t* key_off
     if ((rc = ensure(c, c->byte_id, 256 * 4))) return rc;
     if ((rc = ensure(c, c->bloom, bloom.size() * 4))) return rc;
     if ((rc = ensure(c, c->pmask, pmask.size() * 4))) return rc;
+    if ((rc = ensure(c, c->pmask8, pmask8.size() * 4))) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(c->buckets.p, slots.data(), slots.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->keys.p, keys.data(), keys.size() * 8, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->byte_id.p, byte_id.data(), 256 * 4, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->bloom.p, bloom.data(), bloom.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->pmask.p, pmask.data(), pmask.size() * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->pmask8.p, pmask8.data(), pmask8.size() * 4, hipMemcpyHostToDevice));
     c->bucket_mask = bmask;
     c->key_plane = (uint32_t)key_plane;
     c->max_len = max_len;

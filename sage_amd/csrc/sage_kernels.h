@@ -14,6 +14,7 @@ struct VocabDev {
     const uint32_t* byte_id;  // id of each single-byte key
     const uint32_t* bloom;    // SAGE_BLOOM_BITS-bit presence filter over (length, bytes), two bits per key
     const uint32_t* pmask;    // [SAGE_PMASK_SLOTS] lengths (bit j-1) of the keys whose first 4 bytes hash to the slot
+    const uint32_t* pmask8;   // [SAGE_PMASK8_SLOTS] the same for the first 8 bytes (keys of >= 8 bytes)
     int max_len;
 };
 
@@ -299,6 +300,7 @@ __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ 
         uint32_t bidx[ML + 1];
         uint32_t miss = 0;   // bit (j-1) set when the filter rules length j out
         uint32_t pm = 0xFFFFFFFFu;   // lengths >= 4 that some key with these first 4 bytes has (superset: slots are shared)
+        uint32_t pm8 = 0xFFFFFFFFu;  // lengths >= 8 that some key with these first 8 bytes has; lengths < 8 pass
         uint32_t h = sage_fnv_step(SAGE_FNV_OFFSET, T[0] & 0xFFu);
 #pragma unroll
         for (int j = 2; j <= ML; ++j) {
@@ -306,6 +308,7 @@ __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ 
             h = sage_fnv_step(h, b);
             const uint32_t f = sage_mix32(h);
             if (j == 4) pm = v.pmask[f & (SAGE_PMASK_SLOTS - 1u)];   // issued early: consumed after the last filter test
+            if (j == 8 && ML > 8) pm8 = v.pmask8[f & (SAGE_PMASK8_SLOTS - 1u)] | 0x7Fu;
             wantf[j] = (sage_slot_tag(f) << 25) | ((uint32_t)(j - 1) << 20);
             bidx[j] = f & v.bucket_mask;
             const uint32_t mk = sage_bloom_mask(f);
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ 
             miss |= min(lack, 1u) << (j - 1);
         }
         // candidate lengths: pass the filter, 2 <= j <= lim
-        const uint32_t cand = ~miss & (pm | 0x6u) & ((lim >= 32u ? 0xFFFFFFFFu : ((1u << lim) - 1u)) & ~1u) & (ML >= 32 ? 0xFFFFFFFFu : ((1u << ML) - 1u));
+        const uint32_t cand = ~miss & (pm | 0x6u) & pm8 & ((lim >= 32u ? 0xFFFFFFFFu : ((1u << lim) - 1u)) & ~1u) & (ML >= 32 ? 0xFFFFFFFFu : ((1u << ML) - 1u));
         uint64_t W[NW];
 #pragma unroll
         for (int w = 0; w < NW; ++w) W[w] = (uint64_t)T[2 * w] | ((uint64_t)T[2 * w + 1] << 32);
