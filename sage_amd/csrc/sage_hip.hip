@@ -184,7 +184,7 @@ int match_and_count(sage_ctx* c, int64_t line0, int64_t line1, uint64_t* out_tot
     if ((rc = ensure(c, c->grand_total, 16))) return rc;
 
     VocabDev v{c->buckets.as<uint4>(), c->bucket_mask, c->keys.as<uint64_t>(), c->key_plane, c->byte_id.as<uint32_t>(),
-               c->bloom.as<uint32_t>(), c->pmask.as<uint32_t>(), c->pmask8.as<uint32_t>(), c->max_len};
+               c->bloom.as<uint32_t>(), c->pmask.p, c->pmask8.p, c->max_len};
     if (nb) {
         Prof p(c, SAGE_K_MATCH);
         const uint32_t grid = cdiv(nb, 256);
@@ -689,8 +689,14 @@ int sage_set_vocab(sage_ctx* c, const uint8_t* key_bytes, const int64_t* key_off
     HIP_TRY(c, hipMemcpy(c->keys.p, keys.data(), keys.size() * 8, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->byte_id.p, byte_id.data(), 256 * 4, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->bloom.p, bloom.data(), bloom.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->pmask.p, pmask.data(), pmask.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->pmask8.p, pmask8.data(), pmask8.size() * 4, hipMemcpyHostToDevice));
+    if (max_len <= 16) {   // the matcher instantiations for max_len <= 16 read 16-bit entries
+        std::vector<uint16_t> a(pmask.begin(), pmask.end()), b(pmask8.begin(), pmask8.end());
+        HIP_TRY(c, hipMemcpy(c->pmask.p, a.data(), a.size() * 2, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->pmask8.p, b.data(), b.size() * 2, hipMemcpyHostToDevice));
+    } else {
+        HIP_TRY(c, hipMemcpy(c->pmask.p, pmask.data(), pmask.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->pmask8.p, pmask8.data(), pmask8.size() * 4, hipMemcpyHostToDevice));
+    }
     c->bucket_mask = bmask;
     c->key_plane = (uint32_t)key_plane;
     c->max_len = max_len;

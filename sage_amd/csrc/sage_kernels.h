@@ -3,6 +3,7 @@
 // is a D=50 dot product per (target, context) pair.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "sage_common.h"
 
 struct VocabDev {
@@ -13,8 +14,9 @@ struct VocabDev {
     uint32_t key_plane;       // ids per plane
     const uint32_t* byte_id;  // id of each single-byte key
     const uint32_t* bloom;    // SAGE_BLOOM_BITS-bit presence filter over (length, bytes), two bits per key
-    const uint32_t* pmask;    // [SAGE_PMASK_SLOTS] lengths (bit j-1) of the keys whose first 4 bytes hash to the slot
-    const uint32_t* pmask8;   // [SAGE_PMASK8_SLOTS] the same for the first 8 bytes (keys of >= 8 bytes)
+    const void* pmask;        // [SAGE_PMASK_SLOTS] lengths (bit j-1) of the keys whose first 4 bytes hash to the slot;
+                              // uint16 entries when max_len <= 16 (half the cache footprint), else uint32
+    const void* pmask8;       // [SAGE_PMASK8_SLOTS] the same for the first 8 bytes (keys of >= 8 bytes)
     int max_len;
 };
 
@@ -299,6 +301,7 @@ __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ 
         uint32_t wantf[ML + 1];
         uint32_t bidx[ML + 1];
         uint32_t miss = 0;   // bit (j-1) set when the filter rules length j out
+        using PM = typename std::conditional<(NW <= 2), uint16_t, uint32_t>::type;
         uint32_t pm = 0xFFFFFFFFu;   // lengths >= 4 that some key with these first 4 bytes has (superset: slots are shared)
         uint32_t pm8 = 0xFFFFFFFFu;  // lengths >= 8 that some key with these first 8 bytes has; lengths < 8 pass
         uint32_t h = sage_fnv_step(SAGE_FNV_OFFSET, T[0] & 0xFFu);
@@ -307,8 +310,8 @@ __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ 
             const uint32_t b = (T[(j - 1) >> 2] >> (8 * ((j - 1) & 3))) & 0xFFu;
             h = sage_fnv_step(h, b);
             const uint32_t f = sage_mix32(h);
-            if (j == 4) pm = v.pmask[f & (SAGE_PMASK_SLOTS - 1u)];   // issued early: consumed after the last filter test
-            if (j == 8 && ML > 8) pm8 = v.pmask8[f & (SAGE_PMASK8_SLOTS - 1u)] | 0x7Fu;
+            if (j == 4) pm = reinterpret_cast<const PM*>(v.pmask)[f & (SAGE_PMASK_SLOTS - 1u)];   // issued early, used last
+            if (j == 8 && ML > 8) pm8 = reinterpret_cast<const PM*>(v.pmask8)[f & (SAGE_PMASK8_SLOTS - 1u)] | 0x7Fu;
             wantf[j] = (sage_slot_tag(f) << 25) | ((uint32_t)(j - 1) << 20);
             bidx[j] = f & v.bucket_mask;
             const uint32_t mk = sage_bloom_mask(f);
