@@ -230,6 +230,8 @@ def main():
             "describe": st["corpus_bytes"] * 8 + tokens_local * (8 + 64),
             "pairs": tokens_local * (args.dim * eb + 16),
             "logsig": st["pairs"] * 8 + st["occurrences"] * 64,
+            # float64 recomputation of the occurrences that touch a row the float32 copy cannot hold
+            "fix": st["f64_fix_occurrences"] * (r_bar * args.dim * 8 + 64),
         }
         dom = max(per_kernel_bytes, key=lambda k: kt[k][0])
         dom_ms, dom_n = kt[dom]

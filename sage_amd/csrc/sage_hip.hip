@@ -244,7 +244,7 @@ int padded_dim(int dim) {
 // G x EPL = lanes per row x elements per lane
 template <int G, int EPL, typename T>
 void launch_pairs(sage_ctx* c, const T* emb, const uint32_t* tok_w0, uint32_t n_tok, bool fix) {
-    Prof p(c, SAGE_K_PAIRS);
+    Prof p(c, fix ? SAGE_K_FIX : SAGE_K_PAIRS);
     const uint32_t grid = std::min<uint32_t>(cdiv(cdiv(n_tok, 4), 256 / G), 256u * 16u);
     if (fix)
         k_pair_cache<G, EPL, T, true><<<grid, 256, 0, c->stream>>>(tok_w0, n_tok, emb, (uint32_t)c->emb_rows, (uint32_t)c->dp,
@@ -257,7 +257,7 @@ void launch_pairs(sage_ctx* c, const T* emb, const uint32_t* tok_w0, uint32_t n_
 
 template <int G, int EPL, typename T>
 void launch_dots(sage_ctx* c, const T* emb, uint32_t n_occ, bool listed) {
-    Prof p(c, SAGE_K_SCORE);
+    Prof p(c, listed ? SAGE_K_FIX : SAGE_K_SCORE);
     const uint32_t grid = std::min<uint32_t>(cdiv(n_occ, 256 / G), (uint32_t)c->n_cu * (sizeof(T) == 4 ? 5u : 4u));
     k_dots<G, EPL, T, 5><<<grid, 256, 0, c->stream>>>(
         c->desc.as<uint4>(), c->pool.as<uint32_t>(), n_occ, c->dot_off.as<uint32_t>(), emb, (uint32_t)c->emb_rows,
@@ -310,7 +310,7 @@ void launch_score(sage_ctx* c, const uint32_t* tok_w0, uint32_t n_tok, uint32_t 
     }
     if (fix) {
         SAGE_BY_WIDTH_F64(launch_dots, c, e64, n_occ, true)
-        Prof p(c, SAGE_K_LOGSIG);
+        Prof p(c, SAGE_K_FIX);
         const uint32_t grid = std::min<uint32_t>(cdiv(n_occ, 32), 256u * 8u);
         k_logsig_list<<<grid, 256, 0, c->stream>>>(c->desc.as<uint4>(), c->occ_tok.as<uint32_t>(), tok_w0,
                                                    c->inex_list.as<uint32_t>(), c->inex_count.as<uint32_t>(),
