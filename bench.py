@@ -28,7 +28,7 @@ sys.path.insert(0, str(REPO))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # kernel class (sage_hip.h SAGE_K_*) -> the kernel that dominates it in the rocprofv3 traces under profiles/
-CLASS_KERNEL = {"match": "k_match_lds", "score": "k_dots", "count": "k_key_dedupe", "describe": "k_describe",
+CLASS_KERNEL = {"match": "k_match_lds", "score": "k_dots", "count": "k_key_dedupe", "partition": "k_key_partition<1>", "describe": "k_describe",
                 "pairs": "k_pair_cache", "logsig": "k_logsig", "walk": "k_walk_write"}
 
 
@@ -225,7 +225,8 @@ def main():
         per_kernel_bytes = {   # per step, this rank; DESIGN.md "Kernels" states each figure
             "match": st["corpus_bytes"] * (1 + 1 + 8),
             "walk": st["corpus_bytes"] * 8 / max(1.0, b_bar) * 2 + tokens_local * 8,
-            "count": st["records"] * 8 * 2,
+            "count": st["pairs"] * 8 * 2,          # dedupe: every key record read and written once more (fine partition)
+            "partition": st["pairs"] * 8 + st["occurrences"] * 64,   # key scatter: descriptors in, one 8-byte record per pair out
             "score": st["rows"] * args.dim * eb,
             "describe": st["corpus_bytes"] * 8 + tokens_local * (8 + 64),
             "pairs": tokens_local * (args.dim * eb + 16),

@@ -110,7 +110,8 @@ int sage_ablation_step_device(sage_ctx* ctx, const int64_t* segment_line_bounds,
  */
 enum { SAGE_K_MATCH = 0, SAGE_K_WALK = 1, SAGE_K_SCAN = 2, SAGE_K_COUNT = 3, SAGE_K_SCORE = 4, SAGE_K_MISC = 5,
        SAGE_K_DESCRIBE = 6, SAGE_K_PAIRS = 7, SAGE_K_LOGSIG = 8, SAGE_K_FIX = 9 /* float64 recomputation passes of the
-       float32 row storage */, SAGE_K_NCLASSES = 10 };
+       float32 row storage */, SAGE_K_PARTITION = 10 /* key scatter of the distinct count; SAGE_K_COUNT = its dedupe */,
+       SAGE_K_NCLASSES = 11 };
 int sage_set_profiling(sage_ctx* ctx, int enabled);
 int sage_reset_kernel_times(sage_ctx* ctx);
 int sage_get_kernel_times(sage_ctx* ctx, double* out_ms /*[SAGE_K_NCLASSES]*/, int64_t* out_launches /*[SAGE_K_NCLASSES]*/);

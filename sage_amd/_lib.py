@@ -10,7 +10,7 @@ import numpy as np
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = _HERE / "libsage_hip.so"
 
-K_CLASSES = ("match", "walk", "scan", "count", "score", "misc", "describe", "pairs", "logsig", "fix")
+K_CLASSES = ("match", "walk", "scan", "count", "score", "misc", "describe", "pairs", "logsig", "fix", "partition")
 
 _ERRORS = {-1: ValueError, -2: Exception, -3: RuntimeError, -4: RuntimeError, -5: ValueError, -6: IndexError,
            -7: ValueError}

@@ -423,6 +423,9 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
                     c->seg_pairs.as<unsigned long long>(), c->occ.as<unsigned long long>(),
                     c->hist.as<unsigned long long>(), (uint32_t)hist_len, c->stats.as<unsigned long long>(),
                     c->flags.as<uint32_t>(), c->long_list.as<uint32_t>(), c->long_count.as<uint32_t>());
+            }
+            {
+                Prof p(c, SAGE_K_MISC);   // the long-occurrence kernels are accounted under "misc"
                 k_describe<true><<<lgrid, 256, 0, c->stream>>>(
                     A, c->occ_tok.as<uint32_t>(), n_occ, S, c->desc.as<uint4>(), c->np_ab.as<uint32_t>(),
                     c->pool.as<uint32_t>(), c->pool_cursor.as<uint32_t>(), (uint32_t)pool_cap,
@@ -446,7 +449,7 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
                     // counting pass: exact bucket sizes
                     HIP_TRY(c, hipMemsetAsync(c->hist1.p, 0, nbk * 8, c->stream));
                     {
-                        Prof p(c, SAGE_K_COUNT);
+                        Prof p(c, SAGE_K_PARTITION);
                         k_key_partition<0><<<pgrid, PART_TILE, 0, c->stream>>>(c->desc.as<uint4>(), c->pool.as<uint32_t>(),
                                                                          c->occ_tok.as<uint32_t>(), A.tok_w0, n_occ, S,
                                                                          c->hist1.as<unsigned long long>(), nullptr, nullptr,
@@ -483,16 +486,22 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
                 HIP_TRY(c, hipMemcpyAsync(c->bucket_lim.p, blim.data(), nbk * 8, hipMemcpyHostToDevice, c->stream));
                 HIP_TRY(c, hipMemcpyAsync(c->hist1.p, boff.data(), nbk * 8, hipMemcpyHostToDevice, c->stream));  // cursors
                 {
-                    Prof p(c, SAGE_K_COUNT);
+                    Prof p(c, SAGE_K_PARTITION);
                     k_key_partition<1><<<pgrid, PART_TILE, 0, c->stream>>>(c->desc.as<uint4>(), c->pool.as<uint32_t>(),
                                                                      c->occ_tok.as<uint32_t>(), A.tok_w0, n_occ, S,
                                                                      c->hist1.as<unsigned long long>(),
                                                                      c->rec_a.as<unsigned long long>(),
                                                                      c->bucket_lim.as<unsigned long long>(), c->flags.as<uint32_t>());
+                }
+                {
+                    Prof p(c, SAGE_K_MISC);
                     k_key_partition_long<1><<<lgrid, 256, 0, c->stream>>>(
                         c->desc.as<uint4>(), c->pool.as<uint32_t>(), c->occ_tok.as<uint32_t>(), A.tok_w0,
                         c->long_list.as<uint32_t>(), c->long_count.as<uint32_t>(), S, c->hist1.as<unsigned long long>(),
                         c->rec_a.as<unsigned long long>(), c->bucket_lim.as<unsigned long long>(), c->flags.as<uint32_t>());
+                }
+                {
+                    Prof p(c, SAGE_K_COUNT);
                     const uint32_t dgrid = (uint32_t)std::min<size_t>(nbk, 256u * 4u);
                     k_key_dedupe<<<dgrid, 256, 0, c->stream>>>(c->bucket_off.as<unsigned long long>(),
                                                                c->hist1.as<unsigned long long>(), (uint32_t)nbk,
