@@ -24,7 +24,7 @@ SAGE_HD uint32_t sage_mix32(uint32_t x) {   // one multiply: v_mul_lo_u32 is qua
     return x;
 }
 // A vocab-table slot: id[0:20) | (len-1)[20:25) | tag[25:32).  A bucket is 4 slots (one 16-byte load), filled in
-// order; a bucket whose last slot is empty terminates a probe sequence.
+// order; a bucket whose last slot is empty terminates a probe sequence (load factor <= 0.25, see sage_set_vocab).
 // The 7-bit tag never takes the value 0x7F, so the top 12 bits of a live slot are never 0xFFF: an empty slot
 // (0xFFFFFFFF) cannot pass a tag+length comparison and needs no separate test in the matcher's inner loop.
 SAGE_HD uint32_t sage_slot_tag(uint32_t f) { const uint32_t t = f >> 25; return t < 0x7Eu ? t : 0x7Eu; }
@@ -41,8 +41,12 @@ SAGE_HD uint32_t sage_bloom_mask(uint32_t f) { return (1u << (f & 31u)) | (1u <<
 
 // Prefix-length table of the matcher: slot = mixed hash of a key's first 4 bytes, value = OR of (1 << (len-1)) over the
 // keys of >= 4 bytes that land there.  Collisions only add bits, so it never rules out a real match.
+#ifndef SAGE_PMASK_SLOTS
 #define SAGE_PMASK_SLOTS (1u << 18)
+#endif
+#ifndef SAGE_PMASK8_SLOTS
 #define SAGE_PMASK8_SLOTS (1u << 17)
+#endif
 
 SAGE_HD uint64_t sage_mix64(uint64_t k) {
     k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;

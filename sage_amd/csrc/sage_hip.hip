@@ -646,7 +646,9 @@ int sage_set_vocab(sage_ctx* c, const uint8_t* key_bytes, const int64_t* key_off
     std::vector<uint32_t> byte_id(256, SAGE_SLOT_EMPTY);
     const size_t key_plane = ((size_t)max_id + 1 + 15) & ~(size_t)15;   // ids per 8-byte-word plane
     std::vector<uint64_t> keys(key_plane * 4, 0);
-    const uint64_t nbuckets = pow2ceil(std::max<uint64_t>(16, (uint64_t)n_keys / 2));  // load factor <= 0.5
+    // load factor <= 0.25: a probe of an absent key continues into the next bucket only when this one is full
+    // (2 % of the buckets at this load, 14 % at 0.5), and that continuation is a serial, divergent path in the matcher
+    const uint64_t nbuckets = pow2ceil(std::max<uint64_t>(16, (uint64_t)n_keys));
     std::vector<uint32_t> slots(nbuckets * 4, SAGE_SLOT_EMPTY);
     std::vector<uint32_t> bloom(SAGE_BLOOM_BITS / 32, 0u);
     std::vector<uint32_t> pmask(SAGE_PMASK_SLOTS, 0u), pmask8(SAGE_PMASK8_SLOTS, 0u);
