@@ -248,6 +248,63 @@ __device__ __forceinline__ void probe_chunk(const VocabDev& v, uint32_t cand, co
     }
 }
 
+// Lengths above 8 are sparse once the prefix tables have spoken (a few lanes of a wave have a candidate there, and
+// rarely more than two), so they are not probed column by column: every lane walks ITS OWN candidate lengths from the
+// longest down, one per round, until no lane has any left.  Two or three rounds replace eight columns.
+template <int N>
+__device__ __forceinline__ uint32_t pick_of(const uint32_t* a, uint32_t idx) {   // a[idx], idx < N, registers only
+    uint32_t t[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) t[i] = a[i];
+#pragma unroll
+    for (int sft = 1; sft < N; sft <<= 1) {
+        const bool b = (idx & (uint32_t)sft) != 0u;
+#pragma unroll
+        for (int k = 0; k + sft < N; k += 2 * sft) t[k] = b ? t[k + sft] : t[k];
+    }
+    return t[0];
+}
+
+template <int NW, int JLO, int JHI, int ML>
+__device__ __forceinline__ void probe_sparse(const VocabDev& v, uint32_t cand, const uint32_t (&wantf)[ML + 1],
+                                             const uint32_t (&bidx)[ML + 1], const uint64_t (&W)[NW], Top2& top) {
+    constexpr int N = JHI - JLO + 1;
+    uint32_t c = (cand >> (JLO - 1)) & ((N >= 32) ? 0xFFFFFFFFu : ((1u << N) - 1u));   // bit i <-> length JLO + i
+    while (__any(c != 0u && top.hits < 2u)) {
+        const bool active = c != 0u && top.hits < 2u;
+        const uint32_t i = active ? 31u - (uint32_t)__clz((int)c) : 0u;
+        c = active ? (c & ~(1u << i)) : c;
+        const uint32_t j = (uint32_t)JLO + i;
+        const uint32_t w = pick_of<N>(&wantf[JLO], i), b = pick_of<N>(&bidx[JLO], i);
+        const uint4 bk = v.buckets[active ? b : 0u];
+        const bool m0 = (bk.x ^ w) < (1u << 20), m1 = (bk.y ^ w) < (1u << 20);
+        const bool m2 = (bk.z ^ w) < (1u << 20), m3 = (bk.w ^ w) < (1u << 20);
+        uint32_t x = bk.x;
+        x = m1 ? bk.y : x;
+        x = m2 ? bk.z : x;
+        x = m3 ? bk.w : x;
+        uint32_t id = x & SAGE_ID_MASK;
+        const bool have = active && (m0 | m1 | m2 | m3);
+        bool eq = have;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            const int nb = (int)j - 8 * q;                     // bytes of the key in word q (JLO > 8: word 0 is whole)
+            if (8 * q < JHI) {
+                const uint64_t K = v.keys[(size_t)q * v.key_plane + (have && nb > 0 ? id : 0u)];
+                const uint32_t sh = 64u - 8u * (uint32_t)min(max(nb, 0), 8);
+                eq = eq && (nb <= 0 || ((W[q] ^ K) << (sh & 63u)) == 0ull);
+            }
+        }
+        // rare: a tag match that fails the key compare, or a full bucket without a match -> exact serial probe
+        if (active && !eq && (have || bk.w != SAGE_SLOT_EMPTY)) eq = probe_exact<NW>(v, b, w >> 20, W, (int)j, id);
+        const bool take = active && eq && top.hits < 2u;
+        const bool first = take && top.hits == 0u, second = take && top.hits == 1u;
+        top.id1 = first ? id : top.id1;  top.len1 = first ? j : top.len1;
+        top.id2 = second ? id : top.id2; top.len2 = second ? j : top.len2;
+        top.hits += take ? 1u : 0u;
+    }
+}
+
 template <int NW>
 __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ corpus, const uint8_t* __restrict__ rem,
                                                     int64_t pos0, uint32_t count, VocabDev v, uint2* __restrict__ M) {
@@ -326,17 +383,7 @@ __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ 
         Top2 top{0, 0, 0, 0, 0};
         // chunks from the longest lengths down.  A chunk runs if ANY lane of the wave still needs it (wave-uniform
         // branch); lanes that do not take part are masked through their candidate bits, not through EXEC.
-        if constexpr (NW >= 4) {
-            if (__any((cand >> 24) != 0u)) probe_chunk<NW, 25, 32, ML>(v, cand, wantf, bidx, W, top);
-        }
-        if constexpr (NW >= 3) {
-            const uint32_t c3 = top.hits < 2u ? cand : 0u;
-            if (__any(((c3 >> 16) & 0xFFu) != 0u)) probe_chunk<NW, 17, 24, ML>(v, c3, wantf, bidx, W, top);
-        }
-        if constexpr (NW >= 2) {
-            const uint32_t c2 = top.hits < 2u ? cand : 0u;
-            if (__any(((c2 >> 8) & 0xFFu) != 0u)) probe_chunk<NW, 9, 16, ML>(v, c2, wantf, bidx, W, top);
-        }
+        if constexpr (NW >= 2) probe_sparse<NW, 9, ML, ML>(v, cand, wantf, bidx, W, top);
         {
             const uint32_t c1 = top.hits < 2u ? cand : 0u;
             if (__any((c1 & 0xFFu) != 0u)) probe_chunk<NW, 2, 8, ML>(v, c1, wantf, bidx, W, top);
