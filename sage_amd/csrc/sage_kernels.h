@@ -269,39 +269,56 @@ template <int NW, int JLO, int JHI, int ML>
 __device__ __forceinline__ void probe_sparse(const VocabDev& v, uint32_t cand, const uint32_t (&wantf)[ML + 1],
                                              const uint32_t (&bidx)[ML + 1], const uint64_t (&W)[NW], Top2& top) {
     constexpr int N = JHI - JLO + 1;
+    constexpr int PW = 2;   // candidates a lane probes per round: both bucket loads, then both key loads, in flight together
     uint32_t c = (cand >> (JLO - 1)) & ((N >= 32) ? 0xFFFFFFFFu : ((1u << N) - 1u));   // bit i <-> length JLO + i
     while (__any(c != 0u && top.hits < 2u)) {
-        const bool active = c != 0u && top.hits < 2u;
-        const uint32_t i = active ? 31u - (uint32_t)__clz((int)c) : 0u;
-        c = active ? (c & ~(1u << i)) : c;
-        const uint32_t j = (uint32_t)JLO + i;
-        const uint32_t w = pick_of<N>(&wantf[JLO], i), b = pick_of<N>(&bidx[JLO], i);
-        const uint4 bk = v.buckets[active ? b : 0u];
-        const bool m0 = (bk.x ^ w) < (1u << 20), m1 = (bk.y ^ w) < (1u << 20);
-        const bool m2 = (bk.z ^ w) < (1u << 20), m3 = (bk.w ^ w) < (1u << 20);
-        uint32_t x = bk.x;
-        x = m1 ? bk.y : x;
-        x = m2 ? bk.z : x;
-        x = m3 ? bk.w : x;
-        uint32_t id = x & SAGE_ID_MASK;
-        const bool have = active && (m0 | m1 | m2 | m3);
-        bool eq = have;
+        bool active[PW], have[PW];
+        uint32_t j[PW], w[PW], b[PW], id[PW];
+        uint4 bk[PW];
+        uint64_t K[PW][NW];
 #pragma unroll
-        for (int q = 0; q < NW; ++q) {
-            const int nb = (int)j - 8 * q;                     // bytes of the key in word q (JLO > 8: word 0 is whole)
-            if (8 * q < JHI) {
-                const uint64_t K = v.keys[(size_t)q * v.key_plane + (have && nb > 0 ? id : 0u)];
-                const uint32_t sh = 64u - 8u * (uint32_t)min(max(nb, 0), 8);
-                eq = eq && (nb <= 0 || ((W[q] ^ K) << (sh & 63u)) == 0ull);
-            }
+        for (int r = 0; r < PW; ++r) {
+            active[r] = c != 0u && top.hits < 2u;
+            const uint32_t i = active[r] ? 31u - (uint32_t)__clz((int)c) : 0u;
+            c = active[r] ? (c & ~(1u << i)) : c;
+            j[r] = (uint32_t)JLO + i;
+            w[r] = pick_of<N>(&wantf[JLO], i);
+            b[r] = pick_of<N>(&bidx[JLO], i);
+            bk[r] = v.buckets[active[r] ? b[r] : 0u];
         }
-        // rare: a tag match that fails the key compare, or a full bucket without a match -> exact serial probe
-        if (active && !eq && (have || bk.w != SAGE_SLOT_EMPTY)) eq = probe_exact<NW>(v, b, w >> 20, W, (int)j, id);
-        const bool take = active && eq && top.hits < 2u;
-        const bool first = take && top.hits == 0u, second = take && top.hits == 1u;
-        top.id1 = first ? id : top.id1;  top.len1 = first ? j : top.len1;
-        top.id2 = second ? id : top.id2; top.len2 = second ? j : top.len2;
-        top.hits += take ? 1u : 0u;
+#pragma unroll
+        for (int r = 0; r < PW; ++r) {
+            const bool m0 = (bk[r].x ^ w[r]) < (1u << 20), m1 = (bk[r].y ^ w[r]) < (1u << 20);
+            const bool m2 = (bk[r].z ^ w[r]) < (1u << 20), m3 = (bk[r].w ^ w[r]) < (1u << 20);
+            uint32_t x = bk[r].x;
+            x = m1 ? bk[r].y : x;
+            x = m2 ? bk[r].z : x;
+            x = m3 ? bk[r].w : x;
+            id[r] = x & SAGE_ID_MASK;
+            have[r] = active[r] && (m0 | m1 | m2 | m3);
+#pragma unroll
+            for (int q = 0; q < NW; ++q)
+                if (8 * q < JHI) K[r][q] = v.keys[(size_t)q * v.key_plane + (have[r] && (int)j[r] > 8 * q ? id[r] : 0u)];
+        }
+#pragma unroll
+        for (int r = 0; r < PW; ++r) {   // r = 0 is the longer length
+            bool eq = have[r];
+#pragma unroll
+            for (int q = 0; q < NW; ++q)
+                if (8 * q < JHI) {
+                    const int nb = (int)j[r] - 8 * q;              // bytes of the key in word q (JLO > 8: word 0 is whole)
+                    const uint32_t sh = 64u - 8u * (uint32_t)min(max(nb, 0), 8);
+                    eq = eq && (nb <= 0 || ((W[q] ^ K[r][q]) << (sh & 63u)) == 0ull);
+                }
+            // rare: a tag match that fails the key compare, or a full bucket without a match -> exact serial probe
+            if (active[r] && !eq && (have[r] || bk[r].w != SAGE_SLOT_EMPTY))
+                eq = probe_exact<NW>(v, b[r], w[r] >> 20, W, (int)j[r], id[r]);
+            const bool take = active[r] && eq && top.hits < 2u;
+            const bool first = take && top.hits == 0u, second = take && top.hits == 1u;
+            top.id1 = first ? id[r] : top.id1;  top.len1 = first ? j[r] : top.len1;
+            top.id2 = second ? id[r] : top.id2; top.len2 = second ? j[r] : top.len2;
+            top.hits += take ? 1u : 0u;
+        }
     }
 }
 
