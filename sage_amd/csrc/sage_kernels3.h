@@ -286,6 +286,7 @@ __global__ __launch_bounds__(256) void k_key_dedupe(const unsigned long long* __
     __shared__ unsigned int hist2[NB2_MAX];
     __shared__ unsigned int offs2[NB2_MAX + 1];
     __shared__ unsigned int wsum[4];
+    __shared__ unsigned int chist[NB2_MAX], cstart[NB2_MAX], gpos[NB2_MAX];
     unsigned long long n_distinct = 0;
     for (uint32_t bk = blockIdx.x; bk < n_buckets; bk += gridDim.x) {
         const unsigned long long o0 = bucket_off[bk];
@@ -327,16 +328,64 @@ __global__ __launch_bounds__(256) void k_key_dedupe(const unsigned long long* __
                 if (threadIdx.x == 0) offs2[nb2] = cnt;
             }
             __syncthreads();
-            for (uint32_t i0 = threadIdx.x; i0 < cnt; i0 += 256 * UNR) {
+            // Scatter through LDS, 2,048 records at a time: the chunk is grouped by fine bucket on chip (the dedupe set's
+            // memory is free at this point) and each bucket's run leaves as consecutive 8-byte stores, so HBM sees whole
+            // sectors instead of 256 interleaved streams of partial-line writes.
+            unsigned long long* stage = set;                               // 2,048 x 8 B
+            unsigned short* stage_fb = reinterpret_cast<unsigned short*>(set + 256 * UNR);   // 2,048 x 2 B
+            for (uint32_t c0 = 0; c0 < cnt; c0 += 256 * UNR) {
                 uint64_t kk[UNR];
+                uint32_t fbk[UNR], rk[UNR];
+                if (threadIdx.x < nb2) chist[threadIdx.x] = 0;
+                __syncthreads();
 #pragma unroll
-                for (int u = 0; u < UNR; ++u) kk[u] = (i0 + 256u * u) < cnt ? in[i0 + 256u * u] : 0ull;
+                for (int u = 0; u < UNR; ++u) {
+                    const uint32_t i = c0 + threadIdx.x + 256u * u;
+                    kk[u] = i < cnt ? in[i] : 0ull;
+                }
 #pragma unroll
-                for (int u = 0; u < UNR; ++u)
-                    if ((i0 + 256u * u) < cnt) {
-                        const uint32_t r = atomicAdd(&hist2[(uint32_t)(sage_mix64(kk[u]) >> 6) & (nb2 - 1)], 1u);
-                        tmp[r] = kk[u];
+                for (int u = 0; u < UNR; ++u) {
+                    const uint32_t i = c0 + threadIdx.x + 256u * u;
+                    fbk[u] = (uint32_t)(sage_mix64(kk[u]) >> 6) & (nb2 - 1);
+                    rk[u] = i < cnt ? atomicAdd(&chist[fbk[u]], 1u) : 0u;
+                }
+                __syncthreads();
+                {   // exclusive scan of the chunk histogram; global base of every run
+                    const uint32_t vv = threadIdx.x < nb2 ? chist[threadIdx.x] : 0u;
+                    uint32_t incl = vv;
+                    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#pragma unroll
+                    for (int dd = 1; dd < 64; dd <<= 1) {
+                        const uint32_t nn = __shfl_up(incl, dd, 64);
+                        if (lane >= (uint32_t)dd) incl += nn;
                     }
+                    if (lane == 63) wsum[wave] = incl;
+                    __syncthreads();
+                    uint32_t wbase = 0;
+                    for (uint32_t ww = 0; ww < wave; ++ww) wbase += wsum[ww];
+                    if (threadIdx.x < nb2) {
+                        cstart[threadIdx.x] = wbase + incl - vv;
+                        gpos[threadIdx.x] = hist2[threadIdx.x];
+                        hist2[threadIdx.x] += vv;
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const uint32_t i = c0 + threadIdx.x + 256u * u;
+                    if (i < cnt) {
+                        const uint32_t at = cstart[fbk[u]] + rk[u];
+                        stage[at] = kk[u];
+                        stage_fb[at] = (unsigned short)fbk[u];
+                    }
+                }
+                __syncthreads();
+                const uint32_t nchunk = min(256u * UNR, cnt - c0);
+                for (uint32_t e = threadIdx.x; e < nchunk; e += 256u) {
+                    const uint32_t fb = stage_fb[e];
+                    tmp[gpos[fb] + (e - cstart[fb])] = stage[e];
+                }
+                __syncthreads();
             }
             __threadfence_block();
             __syncthreads();
