@@ -9,7 +9,9 @@
 
 #define DESC_LDS_STRIDE 17  // 16 words + 1 pad: conflict-free per-thread row writes
 #define SEG_LDS 128         // count segments of a batch whose pair totals k_describe accumulates in LDS
-#define DESC_SPAN 3072      // corpus positions of the match table one k_describe tile stages in LDS
+#define DESC_ACC_BITS 10    // k_describe's occurrence-count cache: 1,024 slots (LDS budget: 4 workgroups per CU)
+#define DESC_ACC (1 << DESC_ACC_BITS)
+#define DESC_SPAN 2560      // corpus positions of the match table one k_describe tile stages in LDS
 enum { FLAG_POOL_FULL = 3, FLAG_BUCKET_OVERFLOW = 4 };
 
 // ----------------------------------------------------------------------------------------------------------
@@ -29,8 +31,9 @@ __device__ __forceinline__ void acc_add_f64(uint32_t* cid, double* cval, double*
     if (cur == id) unsafeAtomicAdd(&cval[s], v);
     else unsafeAtomicAdd(&global[id], v);
 }
+template <int BITS = 11>
 __device__ __forceinline__ void acc_add_u32(uint32_t* cid, uint32_t* cval, unsigned long long* __restrict__ global, uint32_t id) {
-    const uint32_t s = acc_slot(id);
+    const uint32_t s = (id * 0x9E3779B1u) >> (32 - BITS);
     uint32_t cur = cid[s];
     if (cur == ACC_EMPTY) cur = atomicCAS(&cid[s], ACC_EMPTY, id), cur = (cur == ACC_EMPTY) ? id : cur;
     if (cur == id) atomicAdd(&cval[s], 1u);
@@ -163,11 +166,11 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
     __shared__ unsigned long long lseg[SEG_LDS];
     __shared__ uint32_t span[LONG ? 1 : DESC_SPAN];   // M[P0 .. P0 + DESC_SPAN).x of the tile: the walks read it from LDS
     __shared__ unsigned int lhist[32];
-    __shared__ uint32_t occ_id[ACC_SLOTS];
-    __shared__ uint32_t occ_n[ACC_SLOTS];
+    __shared__ uint32_t occ_id[DESC_ACC];
+    __shared__ uint32_t occ_n[DESC_ACC];
     if (threadIdx.x < 32) lhist[threadIdx.x] = 0;
     if (threadIdx.x < SEG_LDS) lseg[threadIdx.x] = 0ull;
-    for (uint32_t i = threadIdx.x; i < ACC_SLOTS; i += 256) { occ_id[i] = ACC_EMPTY; occ_n[i] = 0; }
+    for (uint32_t i = threadIdx.x; i < DESC_ACC; i += 256) { occ_id[i] = ACC_EMPTY; occ_n[i] = 0; }
     __syncthreads();
     unsigned long long n_rows = 0, n_pairs = 0;
     const uint32_t n_items = LONG ? *long_count : n_occ;
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
                 my_pairs = (unsigned long long)ab_pairs + window_pairs(w.pl, w.m, w.pr);
                 n_rows += L + w.m;
                 npairs_ab[o] = ab_pairs;
-                acc_add_u32(occ_id, occ_n, occ, w.a);
+                acc_add_u32<DESC_ACC_BITS>(occ_id, occ_n, occ, w.a);
                 const uint32_t kk = w.k < hist_len ? w.k : hist_len - 1u;
                 if (kk < 32u) atomicAdd(&lhist[kk], 1u); else atomicAdd(&hist[kk], 1ull);
             }
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
     __syncthreads();
     if (threadIdx.x < 32 && threadIdx.x < hist_len && lhist[threadIdx.x])
         atomicAdd(&hist[threadIdx.x], (unsigned long long)lhist[threadIdx.x]);
-    for (uint32_t i = threadIdx.x; i < ACC_SLOTS; i += 256)
+    for (uint32_t i = threadIdx.x; i < DESC_ACC; i += 256)
         if (occ_n[i]) atomicAdd(&occ[occ_id[i]], (unsigned long long)occ_n[i]);
     if (threadIdx.x < SEG_LDS && threadIdx.x < S.n_seg && lseg[threadIdx.x]) atomicAdd(&seg_pairs[threadIdx.x], lseg[threadIdx.x]);
 #pragma unroll
