@@ -9,9 +9,9 @@
 
 #define DESC_LDS_STRIDE 17  // 16 words + 1 pad: conflict-free per-thread row writes
 #define SEG_LDS 128         // count segments of a batch whose pair totals k_describe accumulates in LDS
-#define DESC_ACC_BITS 10    // k_describe's occurrence-count cache: 1,024 slots (LDS budget: 4 workgroups per CU)
+#define DESC_ACC_BITS 9    // k_describe's occurrence-count cache: 1,024 slots (LDS budget: 4 workgroups per CU)
 #define DESC_ACC (1 << DESC_ACC_BITS)
-#define DESC_SPAN 2560      // corpus positions of the match table one k_describe tile stages in LDS
+#define DESC_SPAN 2048      // corpus positions of the match table one k_describe tile stages in LDS
 enum { FLAG_POOL_FULL = 3, FLAG_BUCKET_OVERFLOW = 4 };
 
 // ----------------------------------------------------------------------------------------------------------
