@@ -483,7 +483,10 @@ __global__ __launch_bounds__(256) void k_dots(const uint4* __restrict__ desc, co
         meta = 8u | (fj == 0u ? 4u : 0u) | ((fj >= 1u && (c || c1)) ? 1u : 0u) | ((fj >= 2u && (c || c2)) ? 2u : 0u);
         ++fj;
     };
-    uint32_t wr = 0;   // write cursor into dots[]
+    // dots leave eight at a time: lane i of the group keeps the i-th pending dot, one 64-byte store per eight dots
+    // (or per occurrence tail) instead of one 8-byte store per dot
+    uint32_t wr = 0, pend = 0;   // write cursor into dots[] (first pending dot), pending dots
+    double mydot = 0.0;
 #pragma unroll
     for (int i = 0; i < NI; ++i) fetch_id(qid[i], qm[NF + i], qo[NF + i]);
     for (;;) {
@@ -506,20 +509,24 @@ __global__ __launch_bounds__(256) void k_dots(const uint4* __restrict__ desc, co
             if (rid >= emb_rows) { if (rlive) flags[FLAG_ROW_OOB] = 1; rid = 0; }
             load_row_slice<G, EPL>(emb, rid, dp, gl, B[(s + NF) % NS]);
             if (m0 & 8u) {
-                if (m0 & 4u) wr = out0;
+                if (m0 & 4u) {   // a new occurrence: its dots go elsewhere, so the previous one's tail leaves now
+                    if (gl < pend) dots[wr + gl] = mydot;
+                    wr = out0; pend = 0;
+                }
                 if (m0 & 1u) {
                     const double d_ = group_dot<G, EPL, T>(B[s], B[(s + NS - 1) % NS]);
-                    if (gl == 0) dots[wr] = d_;
-                    ++wr;
+                    if (gl == pend) mydot = d_;
+                    if (++pend == 8u) { if (gl < 8u) dots[wr + gl] = mydot; wr += 8u; pend = 0; }
                 }
                 if (m0 & 2u) {
                     const double d_ = group_dot<G, EPL, T>(B[s], B[(s + NS - 2) % NS]);
-                    if (gl == 0) dots[wr] = d_;
-                    ++wr;
+                    if (gl == pend) mydot = d_;
+                    if (++pend == 8u) { if (gl < 8u) dots[wr + gl] = mydot; wr += 8u; pend = 0; }
                 }
             }
         }
     }
+    if (gl < pend) dots[wr + gl] = mydot;
 }
 
 // ----------------------------------------------------------------------------------------------------------
@@ -531,6 +538,8 @@ __global__ __launch_bounds__(256) void k_dots(const uint4* __restrict__ desc, co
 // the base window as a range sum over the pair cache and accumulates per ablated id.
 // ----------------------------------------------------------------------------------------------------------
 #define LOGSIG_TILE 256
+#define LOGSIG_PF 8      // dots of a thread's slice loaded ahead (a tile of 256 occurrences has ~8 dots per thread)
+#define LOGSIG_WIN 6     // pair-cache entries t-2 .. t+3 loaded ahead (centres of up to 4 base tokens)
 __global__ __launch_bounds__(256) void k_logsig(const uint4* __restrict__ desc, const uint32_t* __restrict__ occ_tok,
                                                 const uint32_t* __restrict__ tok_w0, uint32_t n_occ,
                                                 const uint32_t* __restrict__ dot_off, const double* __restrict__ dots,
@@ -560,10 +569,53 @@ __global__ __launch_bounds__(256) void k_logsig(const uint4* __restrict__ desc, 
         uint32_t t = 0;
         if (threadIdx.x < nt) { h = desc[(size_t)o * 4]; t = occ_tok[o]; }
         __syncthreads();
+        // ---- loads of both phases issued together: the pair-cache window of this thread's occurrence (phase 2), the
+        // ablated id, and the first LOGSIG_PF dots of this thread's slice (phase 1) -- one exposed latency per tile
+        const Win w = win_decode(h.x, h.z, h.w);
+        // base window: pair (i,i+1) counts iff i or i+1 is in the centre [t, t+m): rel = i-t in [-1, m-1] clipped to
+        // the window [t-pl, t+m+pr-1]; pair (i,i+2) iff rel in [0,m-1] or rel+2 in [0,m-1] (not contiguous for
+        // m == 1: rel = -1 joins two pads).
+        const int im = (int)w.m, ipl = (int)w.pl, ipr = (int)w.pr;
+        const int lo1 = ipl >= 1 ? -1 : 0, hi1 = im - 2 + (ipr >= 1 ? 1 : 0);
+        const int lo2 = -ipl, hi2 = im + ipr - 3;
+        const bool live = threadIdx.x < nt;
+        const bool small = im <= LOGSIG_WIN - 2;     // rel in [-2, LOGSIG_WIN - 3] covers every term
+        double2 W[LOGSIG_WIN];
+        uint32_t a_w0 = 0;
+        if (live) {
+            a_w0 = tok_w0[t];
+            if (small) {
+#pragma unroll
+                for (int q = 0; q < LOGSIG_WIN; ++q) {
+                    const int rel = q - 2;
+                    W[q] = (rel >= min(lo1, lo2) && rel <= max(hi1, hi2)) ? Gc[(size_t)t + rel] : make_double2(0.0, 0.0);
+                }
+            }
+        }
         const uint32_t d0 = off[0], d1 = off[nt];
         const uint32_t per = (d1 - d0 + 255u) / 256u;
         uint32_t i = d0 + threadIdx.x * per;
         const uint32_t iend = min(d1, i + per);
+        double v[LOGSIG_PF];
+#pragma unroll
+        for (int q = 0; q < LOGSIG_PF; ++q) v[q] = (i + q < iend) ? dots[i + q] : 0.0;
+        double sb = 0.0;
+        if (live) {
+            if (small) {
+#pragma unroll
+                for (int q = 1; q < LOGSIG_WIN; ++q) { const int rel = q - 2; sb += (rel >= lo1 && rel <= hi1) ? W[q].x : 0.0; }
+#pragma unroll
+                for (int q = 0; q < LOGSIG_WIN; ++q) {
+                    const int rel = q - 2;
+                    const bool in = rel >= lo2 && rel <= hi2 && ((rel >= 0 && rel <= im - 1) || (rel + 2 >= 0 && rel + 2 <= im - 1));
+                    sb += in ? W[q].y : 0.0;
+                }
+            } else {
+                for (int rel = lo1; rel <= hi1; ++rel) sb += Gd[((size_t)t + rel) * 2];
+                for (int rel = lo2; rel <= hi2; ++rel)
+                    if ((rel >= 0 && rel <= im - 1) || (rel + 2 >= 0 && rel + 2 <= im - 1)) sb += Gd[((size_t)t + rel) * 2 + 1];
+            }
+        }
         if (i < iend) {
             // owner of dot i: largest j with off[j] <= i
             uint32_t lo = 0, hi = nt;
@@ -574,7 +626,8 @@ __global__ __launch_bounds__(256) void k_logsig(const uint4* __restrict__ desc, 
             uint32_t own = lo, nxt = off[own + 1];
             double acc = 0.0;
             bool bad = false;
-            for (; i < iend; ++i) {
+            uint32_t q = 0;
+            for (; i < iend; ++i, ++q) {
                 if (i >= nxt) {
                     unsafeAtomicAdd(&osum[own], acc);
                     if (bad) obad[own] = 1u;
@@ -582,7 +635,14 @@ __global__ __launch_bounds__(256) void k_logsig(const uint4* __restrict__ desc, 
                     do { ++own; nxt = off[own + 1]; } while (i >= nxt);
                 }
                 // NaN never enters exp/log1p (their special-case paths are slow and a wave takes them for one lane)
-                const double x = dots[i];
+                double x;
+                if (q < LOGSIG_PF) {
+                    x = v[0];
+#pragma unroll
+                    for (int z = 1; z < LOGSIG_PF; ++z) x = (q == (uint32_t)z) ? v[z] : x;
+                } else {
+                    x = dots[i];
+                }
                 const bool isn = x != x;
                 bad = bad || isn;
                 acc += log_sigmoid(isn ? 0.0 : x);
@@ -592,19 +652,8 @@ __global__ __launch_bounds__(256) void k_logsig(const uint4* __restrict__ desc, 
         }
         __syncthreads();
         bool redo = false;
-        if (threadIdx.x < nt) {
-            const Win w = win_decode(h.x, h.z, h.w);
-            const uint32_t a = SAGE_T_ID(tok_w0[t]);
-            // base window: pair (i,i+1) counts iff i or i+1 is in the centre [t, t+m): rel = i-t in [-1, m-1] clipped to
-            // the window [t-pl, t+m+pr-1]; pair (i,i+2) iff rel in [0,m-1] or rel+2 in [0,m-1] (not contiguous for
-            // m == 1: rel = -1 joins two pads).
-            const int im = (int)w.m, ipl = (int)w.pl, ipr = (int)w.pr;
-            const int lo1 = ipl >= 1 ? -1 : 0, hi1 = im - 2 + (ipr >= 1 ? 1 : 0);
-            const int lo2 = -ipl, hi2 = im + ipr - 3;
-            double sb = 0.0;
-            for (int rel = lo1; rel <= hi1; ++rel) sb += Gd[((size_t)t + rel) * 2];
-            for (int rel = lo2; rel <= hi2; ++rel)
-                if ((rel >= 0 && rel <= im - 1) || (rel + 2 >= 0 && rel + 2 <= im - 1)) sb += Gd[((size_t)t + rel) * 2 + 1];
+        if (live) {
+            const uint32_t a = SAGE_T_ID(a_w0);
             const double sum = osum[threadIdx.x];
             redo = fix_list != nullptr && obad[threadIdx.x] != 0u;
             // without a fix list a NaN dot is the caller's own NaN: it goes into the loss as the reference's would
