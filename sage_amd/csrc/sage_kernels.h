@@ -403,7 +403,9 @@ __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ 
         if constexpr (NW >= 2) probe_sparse<NW, 9, ML, ML>(v, cand, wantf, bidx, W, top);
         {
             const uint32_t c1 = top.hits < 2u ? cand : 0u;
-            if (__any((c1 & 0xFFu) != 0u)) probe_chunk<NW, 2, 8, ML>(v, c1, wantf, bidx, W, top);
+            if (__any((c1 & 0xF0u) != 0u)) probe_chunk<NW, 5, 8, ML>(v, c1, wantf, bidx, W, top);
+            const uint32_t c2 = top.hits < 2u ? cand : 0u;
+            if (__any((c2 & 0x0Eu) != 0u)) probe_chunk<NW, 2, 4, ML>(v, c2, wantf, bidx, W, top);
         }
         // the single byte always matches: it is the longest match when nothing else hit, the second when one did
         const uint32_t idb = v.byte_id[T[0] & 0xFFu];
