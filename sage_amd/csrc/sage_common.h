@@ -53,6 +53,21 @@ SAGE_HD uint64_t sage_mix64(uint64_t k) {
     return k;
 }
 
+// Hashes of a 64-bit (a, lo, hi) key record for the distinct count: 32-bit arithmetic only (a 64-bit multiply is six
+// instructions on the GPU, and the partition and dedupe kernels are bound by instruction issue).  hash_a: bits 0-5 the
+// coarse bucket, 6-13 the fine bucket, 14-31 the set pass; hash_b: the slot in an LDS set.  They only spread keys --
+// every set compares whole keys.
+SAGE_HD uint32_t sage_key_hash_a(uint64_t k) {
+    uint32_t h = ((uint32_t)k * 0x9E3779B1u) ^ ((uint32_t)(k >> 32) * 0x85EBCA77u);
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 13;
+    return h;
+}
+SAGE_HD uint32_t sage_key_hash_b(uint64_t k) {
+    uint32_t h = ((uint32_t)k * 0xC2B2AE3Du) + ((uint32_t)(k >> 32) * 0x27D4EB2Fu);
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15;
+    return h;
+}
+
 // A match-table entry per corpus byte: x = id1 | len1<<20 | ends<<31 (longest key at this byte, never crossing the
 // line end; ends = it reaches the line end exactly), y = id2 | len2<<20 (second longest; len2 == 0 iff len1 == 1).
 #define SAGE_M_ID(w) ((w) & SAGE_ID_MASK)

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(PART_TILE) void k_key_partition(const uint4* __rest
         if (live) {
             keys_from_desc<false>(d, pool, tok_w0, t, [&](uint32_t lo, uint32_t hi) {
                 const uint64_t key = make_key(a, lo, hi);
-                const uint32_t b1 = (uint32_t)sage_mix64(key) & (NB1 - 1);
+                const uint32_t b1 = sage_key_hash_a(key) & (NB1 - 1);
                 if (local) atomicAdd(&cnt[seg - s0][b1], 1u);
                 else if (MODE == 0) atomicAdd(&counters[(size_t)seg * NB1 + b1], 1ull);
                 else {
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(PART_TILE) void k_key_partition(const uint4* __rest
             if (local) {
                 keys_from_desc<false>(d, pool, tok_w0, t, [&](uint32_t lo, uint32_t hi) {
                     const uint64_t key = make_key(a, lo, hi);
-                    const uint32_t b1 = (uint32_t)sage_mix64(key) & (NB1 - 1);
+                    const uint32_t b1 = sage_key_hash_a(key) & (NB1 - 1);
                     const uint32_t r = atomicAdd(&cnt[seg - s0][b1], 1u);
                     const unsigned long long gb = gbase[seg - s0][b1];
                     if (gb != ~0ull) rec[gb + r] = key;
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void k_key_partition_long(const uint4* __restr
                 const uint32_t o = __shfl(my_o, (int)(g - e0), 64), t = __shfl(my_t, (int)(g - e0), 64);
                 const uint32_t a = SAGE_T_ID(tok_w0[t]);
                 keys_of_long(desc, pool, tok_w0, o, t, lane, [&](uint32_t lo, uint32_t hi) {
-                    atomicAdd(&cnt[wave][(uint32_t)sage_mix64(make_key(a, lo, hi)) & (NB1 - 1)], 1u);
+                    atomicAdd(&cnt[wave][sage_key_hash_a(make_key(a, lo, hi)) & (NB1 - 1)], 1u);
                 });
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void k_key_partition_long(const uint4* __restr
                     const uint32_t a = SAGE_T_ID(tok_w0[t]);
                     keys_of_long(desc, pool, tok_w0, o, t, lane, [&](uint32_t lo, uint32_t hi) {
                         const uint64_t key = make_key(a, lo, hi);
-                        const uint32_t b1 = (uint32_t)sage_mix64(key) & (NB1 - 1);
+                        const uint32_t b1 = sage_key_hash_a(key) & (NB1 - 1);
                         const uint32_t r = atomicAdd(&cnt[wave][b1], 1u);
                         const unsigned long long gb = gbase[wave][b1];
                         if (gb != ~0ull) rec[gb + r] = key;
@@ -265,8 +265,8 @@ __global__ __launch_bounds__(256) void k_key_partition_long(const uint4* __restr
 }
 
 // ---- pass 3: one block per coarse bucket ---------------------------------------------------------------------
-__device__ __forceinline__ uint32_t lds_set_insert(unsigned long long* set, uint64_t key, uint64_t h, uint32_t* flags) {
-    uint32_t s = (uint32_t)(h >> 32) & (SET_SLOTS - 1);
+__device__ __forceinline__ uint32_t lds_set_insert(unsigned long long* set, uint64_t key, uint32_t* flags) {
+    uint32_t s = sage_key_hash_b(key) & (SET_SLOTS - 1);
     for (uint32_t probes = 0; probes < SET_SLOTS; ++probes) {
         const unsigned long long old = atomicCAS(&set[s], (unsigned long long)SAGE_SET_EMPTY, (unsigned long long)key);
         if (old == SAGE_SET_EMPTY) return ((uint32_t)(key >> 20) & SAGE_ID_MASK) == ((uint32_t)key & SAGE_ID_MASK) ? 1u : 2u;
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void k_key_dedupe(const unsigned long long* __
                 for (int u = 0; u < UNR; ++u) kk[u] = (i0 + 256u * u) < cnt ? in[i0 + 256u * u] : 0ull;
 #pragma unroll
                 for (int u = 0; u < UNR; ++u)
-                    if ((i0 + 256u * u) < cnt) atomicAdd(&hist2[(uint32_t)(sage_mix64(kk[u]) >> 6) & (nb2 - 1)], 1u);
+                    if ((i0 + 256u * u) < cnt) atomicAdd(&hist2[(sage_key_hash_a(kk[u]) >> 6) & (nb2 - 1)], 1u);
             }
             __syncthreads();
             {   // exclusive scan of up to 256 counters by the 256 threads
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void k_key_dedupe(const unsigned long long* __
 #pragma unroll
                 for (int u = 0; u < UNR; ++u) {
                     const uint32_t i = c0 + threadIdx.x + 256u * u;
-                    fbk[u] = (uint32_t)(sage_mix64(kk[u]) >> 6) & (nb2 - 1);
+                    fbk[u] = (sage_key_hash_a(kk[u]) >> 6) & (nb2 - 1);
                     rk[u] = i < cnt ? atomicAdd(&chist[fbk[u]], 1u) : 0u;
                 }
                 __syncthreads();
@@ -408,9 +408,8 @@ __global__ __launch_bounds__(256) void k_key_dedupe(const unsigned long long* __
 #pragma unroll
                     for (int u = 0; u < UNR; ++u)
                         if ((i0 + 256u * u) < fn) {
-                            const uint64_t h = sage_mix64(kk[u]);
-                            if (passes == 1 || ((uint32_t)(h >> 14) & 0x3FFFFu) % passes == p)
-                                n_distinct += lds_set_insert(set, kk[u], h, flags);
+                            if (passes == 1 || (sage_key_hash_a(kk[u]) >> 14) % passes == p)
+                                n_distinct += lds_set_insert(set, kk[u], flags);
                         }
                 }
                 __syncthreads();
