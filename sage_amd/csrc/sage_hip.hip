@@ -258,7 +258,11 @@ void launch_pairs(sage_ctx* c, const T* emb, const uint32_t* tok_w0, uint32_t n_
 template <int G, int EPL, typename T>
 void launch_dots(sage_ctx* c, const T* emb, uint32_t n_occ, bool listed) {
     Prof p(c, listed ? SAGE_K_FIX : SAGE_K_SCORE);
-    const uint32_t grid = std::min<uint32_t>(cdiv(n_occ, 256 / G), (uint32_t)c->n_cu * (sizeof(T) == 4 ? 5u : 4u));
+    // persistent: exactly as many workgroups as the chip holds at once (a partial second round would double the time)
+    static int per_cu = 0;
+    if (per_cu == 0 &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_dots<G, EPL, T, 5>, 256, 0) != hipSuccess) per_cu = 4;
+    const uint32_t grid = std::min<uint32_t>(cdiv(n_occ, 256 / G), (uint32_t)c->n_cu * (uint32_t)std::max(per_cu, 1));
     k_dots<G, EPL, T, 5><<<grid, 256, 0, c->stream>>>(
         c->desc.as<uint4>(), c->pool.as<uint32_t>(), n_occ, c->dot_off.as<uint32_t>(), emb, (uint32_t)c->emb_rows,
         (uint32_t)c->dp, c->dots.as<double>(), c->flags.as<uint32_t>(),

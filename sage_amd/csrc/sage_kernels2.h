@@ -326,16 +326,18 @@ __device__ __forceinline__ void load_row_slice(const float* __restrict__ emb, ui
         r[4 * i] = v.x; r[4 * i + 1] = v.y; r[4 * i + 2] = v.z; r[4 * i + 3] = v.w;
     }
 }
+// (bound_ctrl: every lane of these patterns has a source lane, and without it the compiler zeroes the destination
+// register before every DPP move)
 // Sum over the G lanes of a group, result in every lane.  The first levels are DPP moves inside a 16-lane row
 // (quad_perm xor 1, xor 2, row_half_mirror, row_mirror): VALU only, no trip through the LDS crossbar.
 __device__ __forceinline__ double dpp_add(double v, const int ctrl_sel) {
     int lo = __double2loint(v), hi = __double2hiint(v);
     int plo, phi;
     switch (ctrl_sel) {
-    case 0: plo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, false); phi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, false); break;
-    case 1: plo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, false); phi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, false); break;
-    case 2: plo = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xF, 0xF, false); phi = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xF, 0xF, false); break;
-    default: plo = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xF, 0xF, false); phi = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xF, 0xF, false); break;
+    case 0: plo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true); phi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true); break;
+    case 1: plo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true); phi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true); break;
+    case 2: plo = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xF, 0xF, true); phi = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xF, 0xF, true); break;
+    default: plo = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xF, 0xF, true); phi = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xF, 0xF, true); break;
     }
     return v + __hiloint2double(phi, plo);
 }
@@ -453,6 +455,10 @@ __global__ __launch_bounds__(256) void k_dots(const uint4* __restrict__ desc, co
     constexpr int NF = NS - 3, NI = SAGE_NI, NQ = NF + NI;
     static_assert(NF >= 1, "ring too short");
     T B[NS][EPL];
+    // float32 storage: a row is widened to float64 once, when it becomes current, and kept that way for the two steps
+    // it serves as a predecessor (3 live rows; widening inside the dots costs 32 conversions per step instead of 8)
+    constexpr bool WIDEN = !std::is_same<T, double>::value;
+    double C[WIDEN ? NS : 1][EPL];
     uint32_t qid[NI];           // ids in flight, oldest first
     uint32_t qm[NQ], qo[NQ];    // meta / output offset of every element in flight (rows first, then ids), oldest first
 #pragma unroll
@@ -508,18 +514,26 @@ __global__ __launch_bounds__(256) void k_dots(const uint4* __restrict__ desc, co
             fetch_id(qid[NI - 1], qm[NQ - 1], qo[NQ - 1]);
             if (rid >= emb_rows) { if (rlive) flags[FLAG_ROW_OOB] = 1; rid = 0; }
             load_row_slice<G, EPL>(emb, rid, dp, gl, B[(s + NF) % NS]);
+            if constexpr (WIDEN) {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) C[s][e] = (double)B[s][e];
+            }
             if (m0 & 8u) {
                 if (m0 & 4u) {   // a new occurrence: its dots go elsewhere, so the previous one's tail leaves now
                     if (gl < pend) dots[wr + gl] = mydot;
                     wr = out0; pend = 0;
                 }
                 if (m0 & 1u) {
-                    const double d_ = group_dot<G, EPL, T>(B[s], B[(s + NS - 1) % NS]);
+                    double d_;
+                    if constexpr (WIDEN) d_ = group_dot<G, EPL, double>(C[s], C[(s + NS - 1) % NS]);
+                    else d_ = group_dot<G, EPL, T>(B[s], B[(s + NS - 1) % NS]);
                     if (gl == pend) mydot = d_;
                     if (++pend == 8u) { if (gl < 8u) dots[wr + gl] = mydot; wr += 8u; pend = 0; }
                 }
                 if (m0 & 2u) {
-                    const double d_ = group_dot<G, EPL, T>(B[s], B[(s + NS - 2) % NS]);
+                    double d_;
+                    if constexpr (WIDEN) d_ = group_dot<G, EPL, double>(C[s], C[(s + NS - 2) % NS]);
+                    else d_ = group_dot<G, EPL, T>(B[s], B[(s + NS - 2) % NS]);
                     if (gl == pend) mydot = d_;
                     if (++pend == 8u) { if (gl < 8u) dots[wr + gl] = mydot; wr += 8u; pend = 0; }
                 }
