@@ -483,9 +483,9 @@ __global__ __launch_bounds__(256) void k_dots(const uint4* __restrict__ desc, co
             if (fi < n) { foi = list ? list[fi] : fi; nh = desc[(size_t)foi * 4]; }
         }
         id = fids[fj];
-        const bool c = fj >= fpl && fj < fpl + fk;
-        const bool c1 = (fj - 1u) >= fpl && (fj - 1u) < fpl + fk;   // fj - 1 wraps for fj == 0: false
-        const bool c2 = (fj - 2u) >= fpl && (fj - 2u) < fpl + fk;
+        // element fj is in the centre [pl, pl+k) iff (fj - pl) < k unsigned; the same for its two predecessors
+        const uint32_t u = fj - fpl;
+        const bool c = u < fk, c1 = (u - 1u) < fk, c2 = (u - 2u) < fk;
         meta = 8u | (fj == 0u ? 4u : 0u) | ((fj >= 1u && (c || c1)) ? 1u : 0u) | ((fj >= 2u && (c || c2)) ? 2u : 0u);
         ++fj;
     };
