@@ -264,8 +264,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, args),
                          "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step,
                          "algorithmic_bytes_per_launch": per_kernel_bytes[dom] / launches_per_step,
-                         "note": ("k_match_lds is bound by instruction issue and cache latency (15 prefix hashes + filter and table "
-                                  "probes per corpus byte), not by HBM: see DESIGN.md, Kernels") if dom == "match" else ""},
+                         "note": ("k_match_lds is bound by VALU issue (15 prefix hashes + filter and table probes per corpus "
+                                  "byte; vector pipes ~92 % busy, profiles/r01_v12_sq_cycles.txt), not by HBM: see DESIGN.md, "
+                                  "Kernels") if dom == "match" else ""},
             "step_roofline": {"measured_hbm_bytes_per_step": pmc_traffic("__step_total__", args) if world == 1 else None,
                               "bytes_per_token_A": A, "achieved_GBs_per_gpu": step_gbs, "frac": step_gbs / HBM_PEAK_GBS,
                               "b_bar": b_bar, "f_m": f_m, "r_bar": r_bar, "p_bar": p_bar, "emb_elem_bytes": eb,
