@@ -186,23 +186,27 @@ struct Top2 {
 // Probes the candidate lengths JLO..JHI (at most 8) with all loads of a phase in flight together.  Branch-free:
 // a lane that has no candidate at a length loads bucket 0 / key 0 instead (one shared cache line), which costs
 // far less than the exec-mask bookkeeping of a divergent branch per length.  Lengths are folded into `top`
-// from the longest down.  wantf[j] = (tag << 25) | ((j-1) << 20): a slot matches when slot ^ wantf < 2^20.
+// from the longest down.  want_of(f, j) = (tag << 25) | ((j-1) << 20): a slot matches when slot ^ want < 2^20.
+// fh[j] = finalised hash of the j-byte prefix; bucket index and wanted tag/length word are derived where a length is
+// actually probed (they used to be computed for all 15 lengths up front)
+__device__ __forceinline__ uint32_t want_of(uint32_t f, uint32_t j) { return (sage_slot_tag(f) << 25) | ((j - 1u) << 20); }
+
 template <int NW, int JLO, int JHI, int ML>
-__device__ __forceinline__ void probe_chunk(const VocabDev& v, uint32_t cand, const uint32_t (&wantf)[ML + 1],
-                                            const uint32_t (&bidx)[ML + 1], const uint64_t (&W)[NW], Top2& top) {
+__device__ __forceinline__ void probe_chunk(const VocabDev& v, uint32_t cand, const uint32_t (&fh)[ML + 1],
+                                            const uint64_t (&W)[NW], Top2& top) {
     constexpr int N = JHI - JLO + 1;
     uint4 bk[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         // 0 or ~0 from the candidate bit without going through a condition register
         const uint32_t onm = (uint32_t)(((int32_t)(cand << (32 - (JLO + i)))) >> 31);
-        bk[i] = v.buckets[bidx[JLO + i] & onm];
+        bk[i] = v.buckets[fh[JLO + i] & v.bucket_mask & onm];
     }
     uint32_t cid[N];
     bool have[N], full[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        const uint32_t w = wantf[JLO + i];
+        const uint32_t w = want_of(fh[JLO + i], JLO + i);
         const bool m0 = (bk[i].x ^ w) < (1u << 20), m1 = (bk[i].y ^ w) < (1u << 20);
         const bool m2 = (bk[i].z ^ w) < (1u << 20), m3 = (bk[i].w ^ w) < (1u << 20);
         uint32_t c = bk[i].x;
@@ -235,7 +239,7 @@ __device__ __forceinline__ void probe_chunk(const VocabDev& v, uint32_t cand, co
         for (int i = 0; i < N; ++i)
             if ((slow >> i) & 1u) {
                 uint32_t id;
-                if (probe_exact<NW>(v, bidx[JLO + i], wantf[JLO + i] >> 20, W, JLO + i, id)) { hitm |= 1u << i; cid[i] = id; }
+                if (probe_exact<NW>(v, fh[JLO + i] & v.bucket_mask, want_of(fh[JLO + i], JLO + i) >> 20, W, JLO + i, id)) { hitm |= 1u << i; cid[i] = id; }
             }
     }
 #pragma unroll
@@ -266,8 +270,8 @@ __device__ __forceinline__ uint32_t pick_of(const uint32_t* a, uint32_t idx) {  
 }
 
 template <int NW, int JLO, int JHI, int ML>
-__device__ __forceinline__ void probe_sparse(const VocabDev& v, uint32_t cand, const uint32_t (&wantf)[ML + 1],
-                                             const uint32_t (&bidx)[ML + 1], const uint64_t (&W)[NW], Top2& top) {
+__device__ __forceinline__ void probe_sparse(const VocabDev& v, uint32_t cand, const uint32_t (&fh)[ML + 1],
+                                             const uint64_t (&W)[NW], Top2& top) {
     constexpr int N = JHI - JLO + 1;
     constexpr int PW = 2;   // candidates a lane probes per round: both bucket loads, then both key loads, in flight together
     uint32_t c = (cand >> (JLO - 1)) & ((N >= 32) ? 0xFFFFFFFFu : ((1u << N) - 1u));   // bit i <-> length JLO + i
@@ -282,8 +286,9 @@ __device__ __forceinline__ void probe_sparse(const VocabDev& v, uint32_t cand, c
             const uint32_t i = active[r] ? 31u - (uint32_t)__clz((int)c) : 0u;
             c = active[r] ? (c & ~(1u << i)) : c;
             j[r] = (uint32_t)JLO + i;
-            w[r] = pick_of<N>(&wantf[JLO], i);
-            b[r] = pick_of<N>(&bidx[JLO], i);
+            const uint32_t f = pick_of<N>(&fh[JLO], i);
+            w[r] = want_of(f, j[r]);
+            b[r] = f & v.bucket_mask;
             bk[r] = v.buckets[active[r] ? b[r] : 0u];
         }
 #pragma unroll
@@ -372,8 +377,7 @@ __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ 
             for (int i = 0; i < 2 * NW; ++i) T[i] = __funnelshift_r(d[i], d[i + 1], sh);
         }
         const uint32_t lim = min(rm, (uint32_t)v.max_len);
-        uint32_t wantf[ML + 1];
-        uint32_t bidx[ML + 1];
+        uint32_t fh[ML + 1];
         uint32_t miss = 0;   // bit (j-1) set when the filter rules length j out
         using PM = typename std::conditional<(NW <= 2), uint16_t, uint32_t>::type;
         uint32_t pm = 0xFFFFFFFFu;   // lengths >= 4 that some key with these first 4 bytes has (superset: slots are shared)
@@ -386,8 +390,7 @@ __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ 
             const uint32_t f = sage_mix32(h);
             if (j == 4) pm = reinterpret_cast<const PM*>(v.pmask)[f & (SAGE_PMASK_SLOTS - 1u)];   // issued early, used last
             if (j == 8 && ML > 8) pm8 = reinterpret_cast<const PM*>(v.pmask8)[f & (SAGE_PMASK8_SLOTS - 1u)] | 0x7Fu;
-            wantf[j] = (sage_slot_tag(f) << 25) | ((uint32_t)(j - 1) << 20);
-            bidx[j] = f & v.bucket_mask;
+            fh[j] = f;
             const uint32_t mk = sage_bloom_mask(f);
             const uint32_t lack = (bloom[sage_bloom_word(f)] & mk) ^ mk;      // 0 when both bits are present
             miss |= min(lack, 1u) << (j - 1);
@@ -400,12 +403,12 @@ __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ 
         Top2 top{0, 0, 0, 0, 0};
         // chunks from the longest lengths down.  A chunk runs if ANY lane of the wave still needs it (wave-uniform
         // branch); lanes that do not take part are masked through their candidate bits, not through EXEC.
-        if constexpr (NW >= 2) probe_sparse<NW, 9, ML, ML>(v, cand, wantf, bidx, W, top);
+        if constexpr (NW >= 2) probe_sparse<NW, 9, ML, ML>(v, cand, fh, W, top);
         {
             const uint32_t c1 = top.hits < 2u ? cand : 0u;
-            if (__any((c1 & 0xF0u) != 0u)) probe_chunk<NW, 5, 8, ML>(v, c1, wantf, bidx, W, top);
+            if (__any((c1 & 0xF0u) != 0u)) probe_chunk<NW, 5, 8, ML>(v, c1, fh, W, top);
             const uint32_t c2 = top.hits < 2u ? cand : 0u;
-            if (__any((c2 & 0x0Eu) != 0u)) probe_chunk<NW, 2, 4, ML>(v, c2, wantf, bidx, W, top);
+            if (__any((c2 & 0x0Eu) != 0u)) probe_chunk<NW, 2, 4, ML>(v, c2, fh, W, top);
         }
         // the single byte always matches: it is the longest match when nothing else hit, the second when one did
         const uint32_t idb = v.byte_id[T[0] & 0xFFu];
