@@ -311,9 +311,14 @@ __device__ __forceinline__ void probe_sparse(const VocabDev& v, uint32_t cand, c
 #pragma unroll
             for (int q = 0; q < NW; ++q)
                 if (8 * q < JHI) {
-                    const int nb = (int)j[r] - 8 * q;              // bytes of the key in word q (JLO > 8: word 0 is whole)
-                    const uint32_t sh = 64u - 8u * (uint32_t)min(max(nb, 0), 8);
-                    eq = eq && (nb <= 0 || ((W[q] ^ K[r][q]) << (sh & 63u)) == 0ull);
+                    if (JLO > 8 && JHI <= 16) {   // word 0 is whole, word 1 holds j - 8 = 1..8 bytes: no clamping
+                        if (q == 0) eq = eq && W[0] == K[r][0];
+                        else eq = eq && ((W[q] ^ K[r][q]) << ((16u - j[r]) * 8u)) == 0ull;
+                    } else {
+                        const int nb = (int)j[r] - 8 * q;              // bytes of the key in word q
+                        const uint32_t sh = 64u - 8u * (uint32_t)min(max(nb, 0), 8);
+                        eq = eq && (nb <= 0 || ((W[q] ^ K[r][q]) << (sh & 63u)) == 0ull);
+                    }
                 }
             // rare: a tag match that fails the key compare, or a full bucket without a match -> exact serial probe
             if (active[r] && !eq && (have[r] || bk[r].w != SAGE_SLOT_EMPTY))
