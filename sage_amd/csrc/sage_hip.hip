@@ -39,7 +39,7 @@ struct sage_ctx {
     std::string err;
 
     // vocabulary
-    DevBuf buckets, keys, byte_id, bloom, pmask, pmask8;
+    DevBuf buckets, keys, byte_id, direct2, bloom, pmask, pmask8;
     int match_mode = 0;  // 0 = LDS-filtered persistent matcher, 1 = plain matcher
     uint32_t bucket_mask = 0, key_plane = 0;
     int max_len = 0;
@@ -184,7 +184,7 @@ int match_and_count(sage_ctx* c, int64_t line0, int64_t line1, uint64_t* out_tot
     if ((rc = ensure(c, c->grand_total, 16))) return rc;
 
     VocabDev v{c->buckets.as<uint4>(), c->bucket_mask, c->keys.as<uint64_t>(), c->key_plane, c->byte_id.as<uint32_t>(),
-               c->bloom.as<uint32_t>(), c->pmask.p, c->pmask8.p, c->max_len};
+               c->direct2.as<uint32_t>(), c->bloom.as<uint32_t>(), c->pmask.p, c->pmask8.p, c->max_len};
     if (nb) {
         Prof p(c, SAGE_K_MATCH);
         const uint32_t grid = cdiv(nb, 256);
@@ -622,7 +622,7 @@ void sage_destroy(sage_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     collect_events(c);
     for (auto e : c->ev_free) (void)hipEventDestroy(e);
-    DevBuf* all[] = {&c->buckets, &c->keys, &c->byte_id, &c->bloom, &c->pmask, &c->pmask8, &c->corpus, &c->rem, &c->line_off, &c->emb, &c->M, &c->ntok,
+    DevBuf* all[] = {&c->buckets, &c->keys, &c->byte_id, &c->direct2, &c->bloom, &c->pmask, &c->pmask8, &c->corpus, &c->rem, &c->line_off, &c->emb, &c->M, &c->ntok,
                      &c->tokoff, &c->tile_sums, &c->grand_total, &c->tok_w0, &c->occ_pos, &c->set, &c->seg_line_rel,
                      &c->seg_tok_off, &c->set_base, &c->set_mask, &c->seg_pairs, &c->desc, &c->gcache, &c->hist1, &c->bucket_off, &c->bucket_lim, &c->rec_a, &c->rec_b, &c->nocc, &c->occoff, &c->occ_tok,
                      &c->np_ab, &c->dot_off, &c->dots, &c->pool, &c->pool_cursor, &c->emb32, &c->inexact, &c->inex_list, &c->inex_count, &c->long_list, &c->long_count, &c->w2v_counts, &c->w2v_keep, &c->w2v_dropped, &c->w2v_aprob, &c->w2v_aidx, &c->w2v_syn0, &c->w2v_syn1, &c->ex_ids, &c->ex_starts, &c->ex_widths, &c->loss,
@@ -648,6 +648,7 @@ int sage_set_vocab(sage_ctx* c, const uint8_t* key_bytes, const int64_t* key_off
         max_id = std::max(max_id, id);
     }
     std::vector<uint32_t> byte_id(256, SAGE_SLOT_EMPTY);
+    std::vector<uint32_t> direct2(65536, SAGE_SLOT_EMPTY);   // id of every 2-byte key, indexed by its bytes
     const size_t key_plane = ((size_t)max_id + 1 + 15) & ~(size_t)15;   // ids per 8-byte-word plane
     std::vector<uint64_t> keys(key_plane * 4, 0);
     // load factor <= 0.25: a probe of an absent key continues into the next bucket only when this one is full
@@ -667,6 +668,7 @@ int sage_set_vocab(sage_ctx* c, const uint8_t* key_bytes, const int64_t* key_off
             for (int w = 0; w < 4; ++w) std::memcpy(&keys[(size_t)w * key_plane + id], kb + 8 * w, 8);
         }
         if (len == 1) { byte_id[k[0]] = id; continue; }  // single bytes are looked up directly
+        if (len == 2) direct2[(uint32_t)k[0] | ((uint32_t)k[1] << 8)] = id;   // (and stay in the hash table for k_match)
         uint32_t h = SAGE_FNV_OFFSET;
         for (uint32_t j = 0; j < len; ++j) {
             h = sage_fnv_step(h, k[j]);
@@ -696,6 +698,7 @@ int sage_set_vocab(sage_ctx* c, const uint8_t* key_bytes, const int64_t* key_off
     if ((rc = ensure(c, c->buckets, slots.size() * 4))) return rc;
     if ((rc = ensure(c, c->keys, keys.size() * 8))) return rc;
     if ((rc = ensure(c, c->byte_id, 256 * 4))) return rc;
+    if ((rc = ensure(c, c->direct2, direct2.size() * 4))) return rc;
     if ((rc = ensure(c, c->bloom, bloom.size() * 4))) return rc;
     if ((rc = ensure(c, c->pmask, pmask.size() * 4))) return rc;
     if ((rc = ensure(c, c->pmask8, pmask8.size() * 4))) return rc;
@@ -703,6 +706,7 @@ int sage_set_vocab(sage_ctx* c, const uint8_t* key_bytes, const int64_t* key_off
     HIP_TRY(c, hipMemcpy(c->buckets.p, slots.data(), slots.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->keys.p, keys.data(), keys.size() * 8, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->byte_id.p, byte_id.data(), 256 * 4, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->direct2.p, direct2.data(), direct2.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->bloom.p, bloom.data(), bloom.size() * 4, hipMemcpyHostToDevice));
     if (max_len <= 16) {   // the matcher instantiations for max_len <= 16 read 16-bit entries
         std::vector<uint16_t> a(pmask.begin(), pmask.end()), b(pmask8.begin(), pmask8.end());

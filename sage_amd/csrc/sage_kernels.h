@@ -13,6 +13,7 @@ struct VocabDev {
                               // keys of <= 8 bytes (most matches) touch plane 0 only, 16 keys per 128-B line
     uint32_t key_plane;       // ids per plane
     const uint32_t* byte_id;  // id of each single-byte key
+    const uint32_t* direct2;  // [65536] id of each 2-byte key (index = its two bytes, little-endian), SAGE_SLOT_EMPTY if none
     const uint32_t* bloom;    // SAGE_BLOOM_BITS-bit presence filter over (length, bytes), two bits per key
     const void* pmask;        // [SAGE_PMASK_SLOTS] lengths (bit j-1) of the keys whose first 4 bytes hash to the slot;
                               // uint16 entries when max_len <= 16 (half the cache footprint), else uint32
@@ -382,6 +383,7 @@ __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ 
             for (int i = 0; i < 2 * NW; ++i) T[i] = __funnelshift_r(d[i], d[i + 1], sh);
         }
         const uint32_t lim = min(rm, (uint32_t)v.max_len);
+        const uint32_t d2 = v.direct2[T[0] & 0xFFFFu];
         uint32_t fh[ML + 1];
         uint32_t miss = 0;   // bit (j-1) set when the filter rules length j out
         using PM = typename std::conditional<(NW <= 2), uint16_t, uint32_t>::type;
@@ -413,7 +415,12 @@ __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ 
             const uint32_t c1 = top.hits < 2u ? cand : 0u;
             if (__any((c1 & 0xF0u) != 0u)) probe_chunk<NW, 5, 8, ML>(v, c1, fh, W, top);
             const uint32_t c2 = top.hits < 2u ? cand : 0u;
-            if (__any((c2 & 0x0Eu) != 0u)) probe_chunk<NW, 2, 4, ML>(v, c2, fh, W, top);
+            if (__any((c2 & 0x0Cu) != 0u)) probe_chunk<NW, 3, 4, ML>(v, c2, fh, W, top);
+        }
+        // 2-byte keys need no hash: a 256 KiB table indexed by the two bytes (load issued at the top of the tile)
+        if (top.hits < 2u && lim >= 2u && d2 != SAGE_SLOT_EMPTY) {
+            if (top.hits == 0u) { top.id1 = d2; top.len1 = 2; } else { top.id2 = d2; top.len2 = 2; }
+            ++top.hits;
         }
         // the single byte always matches: it is the longest match when nothing else hit, the second when one did
         const uint32_t idb = v.byte_id[T[0] & 0xFFu];
