@@ -9,6 +9,7 @@
 #include <limits>
 #include <string>
 #include <utility>
+#include <atomic>
 #include <vector>
 
 #include "../../include/sage_hip.h"
@@ -259,9 +260,13 @@ template <int G, int EPL, typename T>
 void launch_dots(sage_ctx* c, const T* emb, uint32_t n_occ, bool listed) {
     Prof p(c, listed ? SAGE_K_FIX : SAGE_K_SCORE);
     // persistent: exactly as many workgroups as the chip holds at once (a partial second round would double the time)
-    static int per_cu = 0;
-    if (per_cu == 0 &&
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_dots<G, EPL, T, 5>, 256, 0) != hipSuccess) per_cu = 4;
+    static std::atomic<int> cached{0};   // per instantiation; the same for every gfx950 device
+    int per_cu = cached.load(std::memory_order_relaxed);
+    if (per_cu == 0) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_dots<G, EPL, T, 5>, 256, 0) != hipSuccess || per_cu < 1)
+            per_cu = 4;
+        cached.store(per_cu, std::memory_order_relaxed);
+    }
     const uint32_t grid = std::min<uint32_t>(cdiv(n_occ, 256 / G), (uint32_t)c->n_cu * (uint32_t)std::max(per_cu, 1));
     k_dots<G, EPL, T, 5><<<grid, 256, 0, c->stream>>>(
         c->desc.as<uint4>(), c->pool.as<uint32_t>(), n_occ, c->dot_off.as<uint32_t>(), emb, (uint32_t)c->emb_rows,
