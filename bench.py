@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import re
 import os
 import sys
 import time
@@ -38,7 +39,9 @@ def pmc_traffic(kernel_class, args):
     16-B-per-lane reads on gfx950).  Only valid for the default workload the passes were taken on; else None."""
     if (args.lines, args.vocab, args.dim, args.max_len, args.style) != (1_000_000, 262_144, 50, 16, "en"):
         return None
-    files = sorted((REPO / "profiles").glob("r*_pmc_traffic.json"))
+    def version_key(path):   # r01_v13 after r01_v9: numbers compared as numbers
+        return [int(x) for x in re.findall(r"\d+", path.name)]
+    files = sorted((REPO / "profiles").glob("r*_pmc_traffic.json"), key=version_key)
     if not files:
         return None
     want = CLASS_KERNEL.get(kernel_class)
