@@ -12,7 +12,8 @@
 #define DESC_ACC_BITS 9    // k_describe's occurrence-count cache: 1,024 slots (LDS budget: 4 workgroups per CU)
 #define DESC_ACC (1 << DESC_ACC_BITS)
 #define DESC_SPAN 2048      // corpus positions of the match table one k_describe tile stages in LDS
-enum { FLAG_POOL_FULL = 3, FLAG_BUCKET_OVERFLOW = 4 };
+enum { FLAG_POOL_FULL = 3, FLAG_BUCKET_OVERFLOW = 4,
+       FLAG_NAN_PAIR = 5 };   // not an error: a base token's float32 row is NaN-marked, the float64 pair pass has work
 
 // ----------------------------------------------------------------------------------------------------------
 // Per-block accumulation cache in LDS for the vocabulary-sized result vectors.  Token frequencies are Zipfian: a few
@@ -397,6 +398,7 @@ __global__ __launch_bounds__(256) void k_pair_cache(const uint32_t* __restrict__
             if (id >= emb_rows) { if (i < n_tok) flags[FLAG_ROW_OOB] = 1; id = 0; }
             ids[j] = id;
         }
+        if (FIX && flags[FLAG_NAN_PAIR] == 0u) return;   // the float32 pass met no marked row: nothing to recompute
         if (FIX) {
             uint32_t mine_id = ids[0];
 #pragma unroll
@@ -406,6 +408,15 @@ __global__ __launch_bounds__(256) void k_pair_cache(const uint32_t* __restrict__
         }
 #pragma unroll
         for (int j = 0; j < 6; ++j) load_row_slice<G, EPL>(emb, ids[j], dp, gl, r[j]);
+        if constexpr (!FIX && std::is_same<T, float>::value) {
+            // a NaN-marked row among the base tokens (lane 0 of the group holds element 0 of every row): tell the float64
+            // pass it has work.  A plain idempotent store -- base tokens are tokens the corpus produces, so with
+            // word2vec-trained embeddings this never fires and the float64 pass returns at once.
+            bool bad = false;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) bad = bad || (i0 + (uint32_t)j < n_tok && r[j][0] != r[j][0]);   // (padding reads row 0)
+            if (bad && gl == 0) flags[FLAG_NAN_PAIR] = 1u;
+        }
         double mine = 0.0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
