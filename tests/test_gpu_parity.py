@@ -144,7 +144,8 @@ def test_fast_sage_lines_golden(tag):
     eng.close()
 
 
-@pytest.mark.parametrize("style,max_len,dim", [("en", 16, 50), ("tr", 17, 50), ("en", 16, 300), ("en", 24, 20)])
+@pytest.mark.parametrize("style,max_len,dim", [("en", 16, 50), ("tr", 17, 50), ("en", 16, 300), ("en", 24, 20), ("en", 8, 50),
+                                               ("en", 32, 64)])
 def test_step_vs_oracle(style, max_len, dim):
     from oracle import sage_oracle as orc
     from sage_amd import synth
