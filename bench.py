@@ -116,13 +116,8 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     def all_reduce_(t, op=None):
-        op = op or dist.ReduceOp.SUM
-        if rehearse:
-            h = t.cpu()
-            dist.all_reduce(h, op=op)
-            t.copy_(h)
-        else:
-            dist.all_reduce(t, op=op)
+        from sage_amd.dist import _through_host
+        _through_host(dist, t, lambda x: dist.all_reduce(x, op=op or dist.ReduceOp.SUM))
 
     from sage_amd import synth
     from sage_amd._lib import HipSage
@@ -172,21 +167,14 @@ def main():
     bounds = segment_line_bounds(len(offsets) - 1, args.workers)
     V = len(vocab)
     H = HipSage.HIST_LEN
-    d_loss = torch.zeros(V, dtype=torch.float64, device="cuda")
-    d_occ = torch.zeros(V, dtype=torch.int64, device="cuda")
-    d_hist = torch.zeros(H, dtype=torch.int64, device="cuda")
-    d_tot = torch.zeros(2, dtype=torch.int64, device="cuda")
+    # the per-step N>1 path is the product's: sage_amd.dist.step_into = sage_ablation_step_device into torch CUDA
+    # tensors, then the combine over the process group (RCCL; staged through the host in the one-GPU rehearsal)
+    from sage_amd.dist import StepBuffers, step_into
+    buf = StepBuffers(V, H)
+    d_tot = buf.tot
 
     def step():
-        eng.ablation_step_device(bounds, (d_loss.data_ptr(), V), d_occ.data_ptr(), d_tot.data_ptr(), (d_hist.data_ptr(), H))
-        if world > 1 and rehearse:
-            from sage_amd.dist import combine_host
-            l, o, h, t = combine_host(dist, d_loss.cpu().numpy(), d_occ.cpu().numpy(), d_hist.cpu().numpy(), d_tot.cpu().numpy())
-            d_loss.copy_(torch.from_numpy(l)); d_occ.copy_(torch.from_numpy(o))
-            d_hist.copy_(torch.from_numpy(h)); d_tot.copy_(torch.from_numpy(t))
-        elif world > 1:
-            from sage_amd.dist import combine_device
-            combine_device(dist, d_loss, d_occ, d_hist, d_tot)
+        step_into(eng, bounds, buf, dist if world > 1 else None)
 
     def fence():
         if world > 1:

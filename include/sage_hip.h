@@ -31,7 +31,7 @@ enum {
     SAGE_E_MISSING_BYTE = -2,/* a single-byte key is absent: model.py:251-255 raises Exception("missing byte") */
     SAGE_E_HIP = -3,         /* a HIP runtime call failed */
     SAGE_E_STATE = -4,       /* vocab / corpus / embeddings not set yet */
-    SAGE_E_LIMIT = -5,       /* a documented limit was exceeded (key longer than 32 bytes, id >= 2^20-1, ...) */
+    SAGE_E_LIMIT = -5,       /* a documented limit was exceeded (max_len above 32, id >= 2^20-1, a batch of 4 GiB, ...) */
     SAGE_E_ROW = -6,         /* a token id indexes past the embedding matrix (numpy IndexError in utils.py:133) */
     SAGE_E_EMPTY_LINE = -7   /* an empty line: model.py:148 cannot unpack zip(*[]) */
 };
@@ -48,8 +48,9 @@ const char* sage_last_error(const sage_ctx* ctx);
  * Replaces SaGeTokenizer.set_vocabulary / set_bytes_vocab / verify_all_single_byte_exist_in_vocab
  * (model.py:28-51, 251-255).  Key i is key_bytes[key_offsets[i] .. key_offsets[i+1]) and gets id key_ids[i]
  * (key_ids == NULL: id = i, the reference's "position in the list").  Keys must be distinct (the Python
- * wrapper resolves repeats the way the dict does).  All 256 single bytes must be present.  Limits: key
- * length 1..32 bytes, ids < 2^20 - 1, max_len 1..32.
+ * wrapper resolves repeats the way the dict does).  All 256 single bytes must be present.  A key longer than
+ * max_len keeps its id but can never match (model.py:90), as in the reference, which only warns about it
+ * (SaGeVocabBuilder.py:52-54).  Limits: ids < 2^20 - 1, max_len 1..32.
  */
 int sage_set_vocab(sage_ctx* ctx, const uint8_t* key_bytes, const int64_t* key_offsets, const int32_t* key_ids,
                    int64_t n_keys, int32_t max_len);
@@ -131,7 +132,9 @@ int sage_set_count_mode(sage_ctx* ctx, int mode);
  * from word2vec (embeddings.py:81) -- are gathered from a float32 copy (half the bytes; products of two float32
  * are exact in float64), and every pair that touches another row (the float64 uniform rows of embeddings.py:86) is
  * recomputed from the float64 matrix; if more than half of the rows are not float32-representable, or a step finds
- * that more than 30 % of the occurrences touch such a row, the float64 matrix is used for everything.  1: float64 storage only.  Takes effect at the next sage_set_embeddings. */
+ * that more than 30 % of the occurrences touch such a row, the float64 matrix is used for everything.  1: float64
+ * storage only.  2: the float32 copy whenever at least one row is float32-representable, whatever the share (a test
+ * switch: it forces the mixed path).  Takes effect at the next sage_set_embeddings, which must follow. */
 int sage_set_score_mode(sage_ctx* ctx, int mode);
 
 /* word2vec retraining on the GPU.  Replaces the host call

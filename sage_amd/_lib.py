@@ -100,6 +100,12 @@ class HipSage:
         self._h = h
         self.device = int(device)
         self.vsize = 0
+        self.hist_len = self.HIST_LEN   # bins of the ablated_sizes histogram; grown by the callers on overflow
+        self.cache = {}                 # what is resident (sage_amd.parallel keeps (object, signature) pairs here)
+
+    def invalidate(self):
+        """Forget what is resident: the next run_sage_parallel uploads vocabulary, corpus and embeddings again."""
+        self.cache.clear()
 
     def close(self):
         if getattr(self, "_h", None):
@@ -125,7 +131,7 @@ class HipSage:
         if flat.size == 0:
             flat = np.zeros(1, dtype=np.uint8)
         off = np.zeros(len(keys) + 1, dtype=np.int64)
-        np.cumsum([len(k) for k in keys], out=off[1:])
+        np.cumsum(np.fromiter(map(len, keys), dtype=np.int64, count=len(keys)), out=off[1:])
         ids_arr = None if ids is None else np.ascontiguousarray(ids, dtype=np.int32)
         self._check(self._lib.sage_set_vocab(self._h, _ptr(flat, C.c_uint8), _ptr(off, C.c_int64),
                                              _ptr(ids_arr, C.c_int32), len(keys), int(max_len)))
@@ -138,12 +144,14 @@ class HipSage:
         self._check(self._lib.sage_set_corpus(self._h, _ptr(buf, C.c_uint8), _ptr(line_offsets, C.c_int64),
                                               len(line_offsets) - 1))
         self.n_lines = len(line_offsets) - 1
+        self.cache.pop("corpus", None)
 
     def set_embeddings(self, emb: np.ndarray):
         emb = np.ascontiguousarray(emb, dtype=np.float64)
         if emb.ndim != 2:
             raise ValueError("embeddings must be [rows, dim]")
         self._check(self._lib.sage_set_embeddings(self._h, _ptr(emb, C.c_double), emb.shape[0], emb.shape[1]))
+        self.cache.pop("emb", None)
 
     # ---- hot path ---------------------------------------------------------------------------------------
     def token_counts(self, line_begin: int, line_end: int):
@@ -165,16 +173,16 @@ class HipSage:
         return ids[:total], starts[:total], widths[:total], counts
 
     def ablation_step(self, segment_line_bounds, pad: int = 2, vsize: int | None = None):
-        """-> (loss f64[vsize], occ i64[vsize], total_tokens, total_triples, hist i64[HIST_LEN])."""
+        """-> (loss f64[vsize], occ i64[vsize], total_tokens, total_triples, hist i64[self.hist_len])."""
         b = np.ascontiguousarray(segment_line_bounds, dtype=np.int64)
         vsize = int(vsize or self.vsize)
         loss = np.zeros(vsize, dtype=np.float64)
         occ = np.zeros(vsize, dtype=np.int64)
-        hist = np.zeros(self.HIST_LEN, dtype=np.int64)
+        hist = np.zeros(self.hist_len, dtype=np.int64)
         tt, ttr = C.c_int64(0), C.c_int64(0)
         self._check(self._lib.sage_ablation_step(self._h, _ptr(b, C.c_int64), len(b) - 1, int(pad),
                                                  _ptr(loss, C.c_double), _ptr(occ, C.c_int64), vsize, C.byref(tt),
-                                                 C.byref(ttr), _ptr(hist, C.c_int64), self.HIST_LEN))
+                                                 C.byref(ttr), _ptr(hist, C.c_int64), self.hist_len))
         return loss, occ, tt.value, ttr.value, hist
 
     def ablation_step_device(self, segment_line_bounds, d_loss, d_occ, d_totals, d_hist, pad: int = 2):
@@ -211,6 +219,7 @@ class HipSage:
     def set_score_mode(self, mode: int):
         """0 = float32 row storage where lossless (default), 1 = float64 storage; call before set_embeddings."""
         self._check(self._lib.sage_set_score_mode(self._h, int(mode)))
+        self.cache.pop("emb", None)     # the library drops its matrix: the next step must upload it again
 
     def train_embeddings(self, vsize: int, dim: int, window: int = 5, negative: int = 15, alpha: float = 0.025,
                          min_alpha: float = 1e-4, epochs: int = 5, sample: float = 1e-3, min_count: int = 1, seed: int = 1):

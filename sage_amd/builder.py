@@ -4,18 +4,47 @@ Same constructor, same `build_vocab` arguments, same files under results/<exp>/ 
 make pruned vocabularies identical: ids are re-compacted after every prune while the embedding matrix is only
 replaced on embeddings_schedule steps (stale rows are indexed by the new ids), single bytes are protected with a
 score of 1e6, targets the active vocabulary already satisfies are skipped, and the cut is the first
-`active - target` entries of sorted((loss, id))."""
+`active - target` entries of sorted((loss, id)).
+
+Under torch.distributed (one process per GPU) every rank runs this loop on the combined, bit-identical loss vector
+and therefore takes the same prune decisions; rank 0 alone writes files and trains embeddings, which are then
+broadcast (`sage_amd.dist`)."""
 from __future__ import annotations
 
 import logging
 from pathlib import Path
-from typing import List, Optional, Union
+from typing import Dict, List, Optional, Tuple, Union
 
+from . import dist as sdist
 from . import hostio
 from .embeddings import get_embeddings
 from .parallel import run_sage_parallel
 from .tokenizer import SaGeTokenizer
 from .w2v_params import Word2VecParams
+
+BYTE_SCORE = 1e6            # SaGeVocabBuilder.py:109
+NEAR_TIE_RTOL = 1e-9        # |delta loss| <= this * |loss| across the cut is reported (float sums are order-dependent)
+
+
+def near_ties_at_cut(ranked: List[Tuple[float, int]], n_prune: int, rtol: float = NEAR_TIE_RTOL):
+    """Entries on both sides of the cut `ranked[:n_prune] | ranked[n_prune:]` whose losses lie within `rtol` of the
+    boundary pair.  The reference's cut is sorted((loss, id))[:k] (SaGeVocabBuilder.py:146,159); its float sums are
+    merged in task-completion order (utils.py:159-183) and ours with atomics, so a pair this close could change
+    sides between runs or GPU counts.  Returns (pruned_side, kept_side) as lists of (loss, id); both empty when the
+    boundary is clear."""
+    if n_prune <= 0 or n_prune >= len(ranked):
+        return [], []
+    below, above = ranked[n_prune - 1][0], ranked[n_prune][0]
+    band = rtol * max(abs(below), abs(above))
+    if above - below > band:
+        return [], []
+    lo = n_prune - 1
+    while lo > 0 and above - ranked[lo - 1][0] <= band:
+        lo -= 1
+    hi = n_prune
+    while hi + 1 < len(ranked) and ranked[hi + 1][0] - below <= band:
+        hi += 1
+    return ranked[lo:n_prune], ranked[n_prune:hi + 1]
 
 
 class SaGeVocabBuilder:
@@ -32,8 +61,15 @@ class SaGeVocabBuilder:
         self.word2vec_params = Word2VecParams(D=word2vec_d, N=word2vec_n, ALPHA=word2vec_alpha,
                                               window_size=word2vec_window_size, min_count=word2vec_min_count,
                                               sg=int(word2vec_sg))
-        # the ablation step; a multi-GPU job swaps in sage_amd.dist.run_sage_distributed
-        self.run_step = run_sage_parallel
+        # the ablation step; None = run_sage_parallel on one GPU, run_sage_distributed under torch.distributed
+        self.run_step = None
+        self.near_ties: Dict[int, tuple] = {}   # target size -> (pruned side, kept side) of a near-tie at the cut
+
+    # ---- one round: score, choose the cut, write the files -------------------------------------------------------
+    def _step_fn(self):
+        if self.run_step is not None:
+            return self.run_step
+        return sdist.run_sage_distributed if sdist.get_dist() else run_sage_parallel
 
     def build_vocab(self, experiment_name: str, corpus_filepath: Union[str, Path], vocabulary_filepath: Union[str, Path],
                     partial_corpus_filepath: Optional[Union[str, Path]] = None, partial_corpus_line_number: int = 1000):
@@ -41,27 +77,28 @@ class SaGeVocabBuilder:
         vocabulary_filepath = Path(vocabulary_filepath)
         # SaGeVocabBuilder.py:38: only a str survives here, a Path argument becomes None
         partial_corpus_filepath = Path(partial_corpus_filepath) if isinstance(partial_corpus_filepath, str) else None
+        rank, world = sdist.world_info()
+        writer = rank == 0
 
-        hostio.init_logger(experiment_name)
-        logging.info(f"Start experiment {experiment_name}")
-        logging.info(f"Process will use up to {self.workers_number} worker threads.")
+        hostio.init_logger(experiment_name, rank)
+        logging.info(f"experiment {experiment_name}: rank {rank} of {world}, workers_number={self.workers_number} "
+                     f"(defines the count segments; the work runs on the GPU)")
         embeddings_folder, stats_folder, vocab_folder = hostio.get_output_folder(experiment_name)
-        hostio.set_random_seed(experiment_name, self.random_seed)
-        logging.info(f"Loading initial vocabulary from file {vocabulary_filepath.as_posix()}")
+        hostio.set_random_seed(experiment_name, self.random_seed, write=writer)
         byte_vocab = hostio.load_vocab(vocabulary_filepath)
-        logging.info(f"Finished loading initial vocabulary. Vocabulary size: {len(byte_vocab)}")
+        logging.info(f"initial vocabulary {vocabulary_filepath.as_posix()}: {len(byte_vocab)} keys")
         longest = max(len(v) for v in byte_vocab)
         if self.max_len != longest:
-            logging.warning(f"max_len parameter value {self.max_len} doesn't match actual max {longest}")
+            logging.warning(f"max_len={self.max_len} differs from the longest key ({longest} bytes)")
         sage_model = SaGeTokenizer(byte_vocab, self.max_len)
-        logging.info(f"Loading Corpus from {corpus_filepath.as_posix()}")
-        partial_corpus = hostio.load_corpus(corpus_filepath, partial_corpus_filepath, partial_corpus_line_number)
+        partial_corpus = hostio.load_corpus_for_rank(corpus_filepath, partial_corpus_filepath,
+                                                     partial_corpus_line_number, rank)
 
         schedule = self.full_vocab_schedule
         if not len(schedule) >= 2:
             raise Exception("Vocabulary schedule must contain more than 2 vocabulary sizes!")
         schedule.sort(reverse=True)  # in place, like the reference (mutates the caller's list)
-        logging.info(f"initial vocab_schedule is {schedule[0]} vs actual size {sage_model.vocab_size()}")
+        logging.info(f"schedule starts at {schedule[0]}; the vocabulary holds {sage_model.vocab_size()} keys")
         retrain_at = set(self.embeddings_schedule)
         # always loaded/trained for the first label, scheduled or not (SaGeVocabBuilder.py:73)
         embeddings = get_embeddings(schedule[0], embeddings_folder, partial_corpus, sage_model, self.workers_number,
@@ -71,64 +108,65 @@ class SaGeVocabBuilder:
             label = schedule[i]
             target = schedule[i + 1]
             actual = sage_model.vocab_size()
-            logging.info(f"\nRound {i} - Start: \n\tCurrent step vocabulary size: {label}, "
-                         f"\n\tTarget vocabulary size: {target}, \n\tActual vocabulary size: {actual}")
+            logging.info(f"round {i}: label {label}, target {target}, vocabulary now {actual}")
             if label in retrain_at:
                 embeddings = get_embeddings(label, embeddings_folder, partial_corpus, sage_model,
                                             self.workers_number, self.word2vec_params)
             if actual <= target:
-                logging.info("Actual vocab is already smaller than target. continue to next iteration ")
+                logging.info("nothing to prune for this target; next round")
                 i += 1
                 continue
 
-            logging.info("Sage started.")
-            total_tokens, total_triples, token_to_losses, ablated_sizes = self.run_step(
+            total_tokens, total_triples, token_to_losses, ablated_sizes = self._step_fn()(
                 embeddings, partial_corpus, sage_model, self.workers_number)
-            logging.info(f"Sage finished. total tokens: {total_tokens}, total triplets: {total_triples}")
+            logging.info(f"ablation step done: {total_tokens} tokens, {total_triples} distinct triples")
 
-            before = len(token_to_losses)
-            sage_model.add_all_byte_ids(token_to_losses, score=1e6)
-            logging.info(f"Adding single bytes to vocab. Size before: {before}, size after: {len(token_to_losses)}")
+            scored = len(token_to_losses)
+            sage_model.add_all_byte_ids(token_to_losses, score=BYTE_SCORE)
             active = len(token_to_losses)
             inactive = actual - active
-            logging.info(f"Actual vocab size: {actual}, Target vocab size: {target}, "
-                         f"Active Vocab Size: {active}, Inactive Vocab Size: {inactive}")
             values = list(token_to_losses.values())
             neg_loss = sum(1 for v in values if v < 0.0)
             zero_loss = sum(1 for v in values if v == 0.0)
             pos_loss = sum(1 for v in values if v > 0.0)
-            logging.info(f"Negative losses: {neg_loss}, zero losses: {zero_loss}, positive losses: {pos_loss}")
+            logging.info(f"{scored} scored ids + single bytes = {active} active, {inactive} inactive; "
+                         f"losses: {neg_loss} negative / {zero_loss} zero / {pos_loss} positive")
 
             while active <= target:  # may run off the end of the schedule with IndexError, as the reference does
-                logging.info(f"Active vocab size is {active} - smaller than target {target}. "
-                             f"Moving to next target_vocab_size\n\n(Round number increased to {i + 1})\n")
                 i += 1
+                logging.info(f"active vocabulary ({active}) already within target {target}: moving to round {i}")
                 target = schedule[i + 1]
-                logging.info(f"New target_vocab_size: {target}")
             n_prune = active - target
-            logging.info(f"Num tokens to prune {n_prune}")
-
             ranked = sorted((loss, tid) for tid, loss in token_to_losses.items())  # ties: ascending id
-            hostio.save_sorted_losses(sage_model, ranked, target, vocab_folder)
-            hostio.save_stats({
-                "current_step_vocab_size": label, "total_tokens": total_tokens, "total_triples": total_triples,
-                "current_active_vocab_size": active, "current_inactive_vocab_size": inactive, "neg_loss": neg_loss,
-                "zero_loss": zero_loss, "pos_loss": pos_loss, "target_vocab_size": target,
-                "num_tokens_to_prune": n_prune, "ablated_sizes": ablated_sizes,
-            }, stats_folder, target)
+            logging.info(f"pruning {n_prune} of {active} down to {target}")
+            tie_low, tie_high = near_ties_at_cut(ranked, n_prune)
+            if tie_low:
+                self.near_ties[target] = (tie_low, tie_high)
+                show = lambda side: ", ".join(f"{sage_model.id_to_encoded(t)}={v!r}" for v, t in side[:8])
+                logging.warning(f"near-tie at the cut for target {target}: {len(tie_low)} pruned [{show(tie_low)}] and "
+                                f"{len(tie_high)} kept [{show(tie_high)}] entries lie within {NEAR_TIE_RTOL:g} relative of "
+                                f"each other; float summation order could move them across the cut")
 
             doomed = {sage_model.id_to_bytes(tid) for _, tid in ranked[:n_prune]}
             assert not any(len(tok) == 1 for tok in doomed)
             vocab_now = sage_model.get_vocabulary()
             survivors = {tok: tid for tok, tid in vocab_now.items() if tok not in doomed}
-            active_vocab = {tok: tid for tok, tid in survivors.items() if tid in token_to_losses}
-            deleted = {tok: tid for tok, tid in vocab_now.items() if tok in doomed}
-            for stem, table in (("sage_vocab", survivors), ("active_vocab", active_vocab), ("deleted_vocab", deleted)):
-                path = vocab_folder / f"{stem}_{target}.vocab"
-                logging.info(f"Saving {stem} of size {len(table)} to {path.as_posix()}")
-                hostio.write_vocab(table, path)
+            if writer:
+                hostio.save_sorted_losses(sage_model, ranked, target, vocab_folder)
+                hostio.save_stats({
+                    "current_step_vocab_size": label, "total_tokens": total_tokens, "total_triples": total_triples,
+                    "current_active_vocab_size": active, "current_inactive_vocab_size": inactive, "neg_loss": neg_loss,
+                    "zero_loss": zero_loss, "pos_loss": pos_loss, "target_vocab_size": target,
+                    "num_tokens_to_prune": n_prune, "ablated_sizes": ablated_sizes,
+                }, stats_folder, target)
+                active_vocab = {tok: tid for tok, tid in survivors.items() if tid in token_to_losses}
+                deleted = {tok: tid for tok, tid in vocab_now.items() if tok in doomed}
+                for stem, table in (("sage_vocab", survivors), ("active_vocab", active_vocab), ("deleted_vocab", deleted)):
+                    path = vocab_folder / f"{stem}_{target}.vocab"
+                    logging.info(f"{path.as_posix()}: {len(table)} keys")
+                    hostio.write_vocab(table, path)
             # ids are re-compacted here; `embeddings` is NOT remapped (stale rows, SaGeVocabBuilder.py:89-91,192)
             sage_model.set_vocabulary(list(survivors.keys()))
-            logging.info(f"\nRound {i} - End: \n\tCurrent step vocabulary size: {label}, "
-                         f"\n\tTarget vocabulary size: {target}, \n\tActual vocabulary size:{len(active_vocab)}")
+            logging.info(f"round {i} finished: {len(survivors)} keys remain ({target} of them active)")
             i += 1
+        sdist.barrier()

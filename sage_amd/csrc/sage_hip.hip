@@ -72,7 +72,8 @@ struct sage_ctx {
         nocc, occoff, occ_tok, np_ab, dot_off, dots, pool, pool_cursor;
     int pool_factor = 8;  // id-pool words per occurrence (grown on overflow)
     bool exact_buckets = false;   // v2 count: size the key buckets with a counting pass instead of the estimate
-    int count_mode = 0;  // 0 = partition + LDS dedupe (v2), 1 = per-segment HBM sets (v1, also the overflow fallback)
+    int count_mode = 0;  // 0 = partition + LDS dedupe (v2), 1 = per-segment HBM sets (v1)
+    bool count_fallback = false;   // an LDS set overflowed: v1 until the vocabulary or the corpus changes
     DevBuf ex_ids, ex_starts, ex_widths;
     DevBuf loss, occ, hist, stats, flags;
     int64_t batch_bytes = 256ll << 20;
@@ -446,7 +447,7 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
             if ((rc = scan_u32(c, c->np_ab.as<uint32_t>(), n_occ, c->dot_off.as<uint32_t>(), c->grand_total.as<uint64_t>() + 1))) return rc;
 
             uint64_t n_dots = 0;
-            if (c->count_mode == 0) {
+            if (c->count_mode == 0 && !c->count_fallback) {
                 // ---- v2: hash-partition the key stream, dedupe each bucket in LDS ----
                 const size_t nbk = (size_t)nsb * NB1;
                 if ((rc = ensure(c, c->hist1, nbk * 8))) return rc;
@@ -569,8 +570,8 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
             continue;
         }
         if (flags[FLAG_SET_OVERFLOW]) {
-            if (c->count_mode == 1) return fail(c, SAGE_E_LIMIT, "distinct-key set overflowed");
-            c->count_mode = 1;   // exactness first: an LDS set overflowed (adversarial hash skew) -> redo with HBM sets
+            if (c->count_mode == 1 || c->count_fallback) return fail(c, SAGE_E_LIMIT, "distinct-key set overflowed");
+            c->count_fallback = true;   // exactness first: an LDS set overflowed (adversarial hash skew) -> redo with HBM sets
             continue;
         }
         if (flags[FLAG_ROW_OOB])
@@ -649,7 +650,9 @@ int sage_set_vocab(sage_ctx* c, const uint8_t* key_bytes, const int64_t* key_off
         const int64_t id = key_ids ? key_ids[i] : i;
         const int64_t len = key_offsets[i + 1] - key_offsets[i];
         if (id < 0 || id > (int64_t)SAGE_MAX_ID) return fail(c, SAGE_E_LIMIT, "token ids must be below 2^20 - 1");
-        if (len < 1 || len > SAGE_MAX_KEY_LEN) return fail(c, SAGE_E_LIMIT, "keys must be 1..32 bytes long");
+        if (len < 1) return fail(c, SAGE_E_ARG, "empty key");
+        // a key longer than max_len can never match (model.py:90 tries lengths max_len..1 only; the reference merely
+        // warns about such a vocabulary, SaGeVocabBuilder.py:52-54): it keeps its id but is left out of every table
         max_id = std::max(max_id, id);
     }
     std::vector<uint32_t> byte_id(256, SAGE_SLOT_EMPTY);
@@ -667,6 +670,7 @@ int sage_set_vocab(sage_ctx* c, const uint8_t* key_bytes, const int64_t* key_off
         const uint32_t id = (uint32_t)(key_ids ? key_ids[i] : i);
         const uint8_t* k = key_bytes + key_offsets[i];
         const uint32_t len = (uint32_t)(key_offsets[i + 1] - key_offsets[i]);
+        if (len > (uint32_t)max_len) continue;
         {
             uint8_t kb[SAGE_MAX_KEY_LEN] = {0};
             std::memcpy(kb, k, len);
@@ -726,6 +730,8 @@ int sage_set_vocab(sage_ctx* c, const uint8_t* key_bytes, const int64_t* key_off
     c->max_len = max_len;
     c->max_id = max_id;
     c->have_vocab = true;
+    c->exact_buckets = false;      // fallbacks a step took because of the old vocabulary's key statistics
+    c->count_fallback = false;
     return SAGE_OK;
 }
 
@@ -759,6 +765,8 @@ int sage_set_corpus(sage_ctx* c, const uint8_t* bytes, const int64_t* line_offse
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     c->have_corpus = true;
+    c->exact_buckets = false;
+    c->count_fallback = false;
     return SAGE_OK;
 }
 

@@ -24,18 +24,24 @@ from .w2v_params import Word2VecParams
 
 def get_embeddings(vocab_size: int, embeddings_folder, partial_corpus, sage_model, workers_number: int,
                    word2vec_params: Word2VecParams) -> np.ndarray:
-    logging.info(f"training Embeddings at vocab size {vocab_size}")
-    path = Path(embeddings_folder) / f"embeddings_{vocab_size}.npy"
-    if path.exists():
-        logging.info(f"Found trained embeddings. Loading it from {path.as_posix()}")
-        return np.load(path.as_posix())
-    logging.info("Start training embeddings with Word2Vec...")
-    started = time.time()
-    emb = train_embeddings(sage_model, partial_corpus, workers_number, word2vec_params)
-    logging.info(f"Embeddings time: {time.time() - started}")
-    logging.info(f"Save embeddings to {path.as_posix()}")
-    np.save(path.as_posix(), emb, allow_pickle=True)
-    return emb
+    """embeddings.py:28-43: load `embeddings_<label>.npy` if it is there, else train and save it.  In a multi-GPU run
+    rank 0 alone loads or trains (and writes the checkpoint); the matrix is then broadcast, so every rank scores its
+    shard with the same rows and the saved file reproduces the run."""
+    from . import dist as sdist
+    rank, _ = sdist.world_info()
+    emb = None
+    if rank == 0:
+        path = Path(embeddings_folder) / f"embeddings_{vocab_size}.npy"
+        if path.exists():
+            logging.info(f"embeddings for label {vocab_size}: loading {path.as_posix()}")
+            emb = np.load(path.as_posix())
+        else:
+            logging.info(f"embeddings for label {vocab_size}: no checkpoint, training word2vec")
+            started = time.time()
+            emb = train_embeddings(sage_model, partial_corpus, workers_number, word2vec_params)
+            logging.info(f"word2vec took {time.time() - started:.1f} s; saving {path.as_posix()}")
+            np.save(path.as_posix(), emb, allow_pickle=True)
+    return sdist.broadcast_array(emb, src=0)
 
 
 def write_gensim_corpus(sage_model, partial_corpus, out_path: Path, lines_per_call: int = 200_000) -> None:
@@ -85,14 +91,13 @@ def fill_matrix(sage_model, D: int, vector_of) -> np.ndarray:
 
 def train_embeddings_hip(sage_model, partial_corpus, word2vec_params: Word2VecParams, seed: int = 1) -> np.ndarray:
     """word2vec on the GPU over the resident corpus (sage_train_embeddings)."""
-    from .parallel import _state, get_engine, sync_corpus, sync_vocab
+    from .parallel import get_engine, sync_corpus, sync_vocab
     if not word2vec_params.sg:
         raise ValueError("the HIP word2vec back end implements skip-gram (sg=1), the reference's setting")
     engine = get_engine()
-    slot = _state[engine.device]
-    sync_vocab(engine, sage_model, slot)
-    sync_corpus(engine, partial_corpus, slot)
-    vsize = max(sage_model.byte_vocab.values()) + 1
+    sync_vocab(engine, sage_model)
+    sync_corpus(engine, partial_corpus)     # the whole corpus (a multi-GPU rank re-uploads its shard at the next step)
+    vsize = sage_model.id_space()
     vec, counts = engine.train_embeddings(vsize, word2vec_params.D, window=word2vec_params.window_size,
                                           negative=word2vec_params.N, alpha=word2vec_params.ALPHA,
                                           min_alpha=GENSIM_MIN_ALPHA, epochs=GENSIM_EPOCHS, sample=GENSIM_SAMPLE,
@@ -116,12 +121,12 @@ def train_embeddings_gensim(sage_model, partial_corpus: List[str], workers: int,
                           "results/<exp>/embeddings/embeddings_<label>.npy for every label that is used") from exc
     corpus_file = getDataFolder() / f"gensim_{sage_model.vocab_size()}.txt"
     if corpus_file.exists():
-        logging.info(f"Gensim format data file already exists: {corpus_file.as_posix()}")
+        logging.info(f"reusing the gensim corpus file {corpus_file.as_posix()}")
     else:
         started = time.time()
-        logging.info(f"starting tokenization of {len(partial_corpus)} lines for gensim")
+        logging.info(f"tokenizing {len(partial_corpus)} lines on the GPU for gensim")
         write_gensim_corpus(sage_model, partial_corpus, corpus_file)
-        logging.info(f"Gensim format data written: {corpus_file.as_posix()}, time: {(time.time() - started):.2f}")
+        logging.info(f"{corpus_file.as_posix()} written in {(time.time() - started):.2f} s")
     w2v = gensim.models.Word2Vec(corpus_file=corpus_file.as_posix(), vector_size=word2vec_params.D,
                                  negative=word2vec_params.N, alpha=word2vec_params.ALPHA,
                                  window=word2vec_params.window_size, min_count=word2vec_params.min_count,

@@ -51,6 +51,7 @@ class SaGeTokenizer:
         enc = self.hfe.to_encoded
         self.str_vocab = {enc(k): i for k, i in table.items()}
         self.inv_str_vocab = {i: s for s, i in self.str_vocab.items()}
+        self._id_space = len(new_vocab)     # ids are list positions (model.py:44-51)
         self.vocab_version += 1
 
     def id_to_bytes(self, token_id: int) -> bytes:
@@ -64,6 +65,10 @@ class SaGeTokenizer:
 
     def vocab_size(self) -> int:
         return len(self.byte_vocab)
+
+    def id_space(self) -> int:
+        """Largest id + 1: the length of the id-indexed result vectors (== vocab_size() unless a key was repeated)."""
+        return self._id_space
 
     def print_tokens(self, ids: List[int]) -> List[bytes]:
         return [self.inv_byte_vocab[i] for i in ids]

@@ -210,9 +210,118 @@ def case_build_vocab():
     print("build_vocab files:", sorted(files.keys()))
 
 
+def case_c1():
+    """BASELINE.json configs[0] exactly: 10k-line partial corpus, 16,384 -> 8,192 keys, one ablation step, D=50,
+    workers=4 (window 5 only reaches gensim), through the reference's whole build_vocab with a
+    pre-seeded embeddings_16384.npy.  The inputs are regenerated from seeds by the test (sha256 pinned here); the
+    outputs are every file the reference wrote."""
+    import hashlib
+    n_lines, V = 10_000, 16_384
+    corpus, off = synth.make_corpus(n_lines, seed=SEED + 101, style="en", n_types=50_000)
+    vocab = synth.make_vocab(corpus, off, V, 16, sample_bytes=6_000_000)
+    assert len(vocab) == V
+    emb_seed = SEED + 102
+    with tempfile.TemporaryDirectory() as tmp:
+        tmp = Path(tmp)
+        setSageFolder(tmp)
+        exp = "c1"
+        (tmp / "results" / exp / "embeddings").mkdir(parents=True)
+        np.save(tmp / "results" / exp / "embeddings" / f"embeddings_{V}.npy", synth.make_embeddings(V, 50, seed=emb_seed))
+        vocab_file = tmp / "initial.vocab"
+        vocab_file.write_text("".join(v.hex() + "\n" for v in vocab))
+        (tmp / "corpus.txt").write_bytes(corpus.tobytes())
+        (tmp / "partial.txt").write_bytes(corpus.tobytes())   # pre-existing partial corpus => no shuffle
+        builder = SaGeVocabBuilder([V, 8192], [V], max_len=16, workers_number=4, random_seed=SEED,
+                                   word2vec_d=50, word2vec_window_size=5)
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            builder.build_vocab(exp, str(tmp / "corpus.txt"), str(vocab_file), str(tmp / "partial.txt"), 10)
+        finally:
+            os.chdir(cwd)
+        res = tmp / "results" / exp
+        files = {}
+        for sub in ("sage_vocabs", "stats"):
+            for p in sorted((res / sub).iterdir()):
+                if p.name.startswith(("worst_500", "best_500")):
+                    continue                      # slices of sorted_losses_before_, pinned by the small golden already
+                files[f"{sub}/{p.name}"] = p.read_text(encoding="utf-8")
+    rec = {"n_lines": n_lines, "vocab_size": V, "schedule": [V, 8192], "embeddings_schedule": [V], "workers": 4,
+           "max_len": 16, "dim": 50, "corpus_seed": SEED + 101, "n_types": 50_000, "emb_seed": emb_seed,
+           "corpus_sha256": hashlib.sha256(corpus.tobytes()).hexdigest(),
+           "vocab_sha256": hashlib.sha256(b"\n".join(v.hex().encode() for v in vocab)).hexdigest(), "files": files}
+    with gzip.open(HERE / "c1_build_vocab.json.gz", "wt") as f:
+        json.dump(rec, f, separators=(",", ":"))
+    print("c1 files:", {k: len(v) for k, v in files.items()})
+    print(files["stats/stats_8192.json"])
+
+
+def case_gensim_file():
+    """The data/gensim_<V>.txt the reference writes BEFORE it touches gensim (embeddings.py:53-66): with the empty
+    gensim stub, train_embeddings tokenizes every line, writes the file and only then fails on
+    gensim.models.Word2Vec (AttributeError), which is caught here."""
+    from sage_tokenizer import embeddings as ref_emb
+    from sage_tokenizer.Word2VecParams import Word2VecParams
+    rec = {}
+    for tag in ("en16", "tr17"):
+        g = np.load(HERE / f"tokenize_{tag}.npz")
+        vb, vo, lb, lo = g["vocab_bytes"].tobytes(), g["vocab_off"], g["line_bytes"].tobytes(), g["line_off"]
+        vocab = [vb[vo[i]:vo[i + 1]] for i in range(len(vo) - 1)]
+        lines = []
+        for i in range(len(lo) - 1):
+            try:
+                lines.append(lb[lo[i]:lo[i + 1]].decode("utf-8"))    # partial_corpus is List[str]
+            except UnicodeDecodeError:
+                pass                                                  # (the golden holds a raw b"\x00\xff" line)
+        model = SaGeTokenizer(vocab, int(g["max_len"]))
+        with tempfile.TemporaryDirectory() as tmp:
+            setSageFolder(Path(tmp))
+            try:
+                ref_emb.train_embeddings(model, lines, 1, Word2VecParams(50, 15, 0.025, 5, 1, 1))
+                raise SystemExit("expected the stubbed gensim to fail after the file was written")
+            except AttributeError:
+                pass
+            text = (Path(tmp) / "data" / f"gensim_{model.vocab_size()}.txt").read_text(encoding="utf-8")
+        rec[tag] = {"lines": lines, "vocab_size": model.vocab_size(), "text": text}
+        print(f"gensim file {tag}: {len(lines)} lines, {len(text)} chars")
+    with gzip.open(HERE / "gensim_file.json.gz", "wt") as f:
+        json.dump(rec, f, separators=(",", ":"), ensure_ascii=False)
+
+
+def case_load_corpus():
+    """load_corpus (utils.py:71-103): shuffle order under a seed, the [:N*1000] slice, the saved partial-corpus file,
+    the reload path, a last line without a newline, multi-byte text."""
+    import hashlib
+    import random
+    corpus, off = synth.make_corpus(2600, seed=SEED + 201, style="tr", n_types=800, mean_log_words=1.2, sigma_log_words=0.5)
+    text = corpus.tobytes()[:-1]          # the last line loses its newline
+    rec = {"corpus_seed": SEED + 201, "cases": []}
+    for seed, k in ((7, 2), (692653, 1), (11, 5)):
+        with tempfile.TemporaryDirectory() as tmp:
+            tmp = Path(tmp)
+            setSageFolder(tmp)
+            (tmp / "wiki.txt").write_bytes(text)
+            random.seed(seed)
+            got = ref_utils.load_corpus(tmp / "wiki.txt", None, k)
+            saved = sorted((tmp / "data").iterdir())
+            assert len(saved) == 1
+            file_bytes = saved[0].read_bytes()
+            again = ref_utils.load_corpus(tmp / "wiki.txt", saved[0], k)
+            assert file_bytes == "".join(got).encode("utf-8")     # writelines(partial): the file is the lines back to back
+            rec["cases"].append({"seed": seed, "k": k, "n": len(got), "file_name": saved[0].name,
+                                 "lines": got, "file_sha256": hashlib.sha256(file_bytes).hexdigest(),
+                                 "reload_n": len(again), "reload_last": again[-1], "reload_equal": again == got})
+            print(f"load_corpus seed={seed} k={k}: {len(got)} lines, file {saved[0].name} {len(file_bytes)} B, reload {len(again)} lines")
+    rec["corpus_sha256"] = hashlib.sha256(text).hexdigest()
+    rec["corpus_args"] = {"n_lines": 2600, "style": "tr", "n_types": 800, "mean_log_words": 1.2, "sigma_log_words": 0.5}
+    with gzip.open(HERE / "load_corpus.json.gz", "wt") as f:
+        json.dump(rec, f, separators=(",", ":"), ensure_ascii=False)
+
+
 def main():
-    if len(sys.argv) > 1 and sys.argv[1] == "build_vocab":
-        case_build_vocab()
+    single = {"build_vocab": case_build_vocab, "c1": case_c1, "gensim_file": case_gensim_file, "load_corpus": case_load_corpus}
+    if len(sys.argv) > 1:          # regenerate one fixture without touching the others
+        single[sys.argv[1]]()
         return
     vocab, lines, model = case_tokenize("en", 16, 3000, 110, "en16")
     case_fast_sage(vocab, lines, model, 16, "en16")
@@ -220,6 +329,9 @@ def main():
     case_fast_sage(vocab, lines, model, 17, "tr17", n_lines=25)
     case_parallel()
     case_build_vocab()
+    case_gensim_file()
+    case_load_corpus()
+    case_c1()
     for p in sorted(HERE.iterdir()):
         print(f"{p.name:32s} {p.stat().st_size:>9d} B")
 

@@ -63,6 +63,23 @@ def _rank_main(rank, world, port, out_dir):
     bounds = segment_line_bounds(len(lines), 3, flush=25)
     loss, occ, tt, ttr, hist = run_sharded_step(dist, bounds, off, _oracle_step(lines, vocab, emb, len(vocab)))
     np.savez(Path(out_dir) / f"rank{rank}.npz", loss=loss, occ=occ, tt=tt, ttr=ttr, hist=hist)
+    # host-side pieces of a multi-rank build_vocab: rank 0's embeddings reach every rank; every rank loads the same
+    # partial corpus and only rank 0 writes its file
+    import random
+    from sage_amd import hostio, setSageFolder
+    from sage_amd.dist import broadcast_array, world_info
+    assert world_info() == (rank, world)
+    got = broadcast_array(emb if rank == 0 else None, src=0)
+    assert got.dtype == emb.dtype and np.array_equal(got, emb)
+    root = Path(out_dir) / f"sage_rank{rank}"
+    root.mkdir()
+    setSageFolder(root)
+    (root / "c.txt").write_bytes(corpus.tobytes())
+    random.seed(99)
+    part = hostio.load_corpus_for_rank(root / "c.txt", None, 1, rank)        # all 180 lines, shuffled
+    assert len(part) == 180
+    np.savez(Path(out_dir) / f"corpus{rank}.npz", data=part.data, off=part.offsets,
+             wrote=(root / "data" / "c_180.txt").exists())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -84,3 +101,6 @@ def test_two_rank_combine_equals_one_rank(tmp_path):
         assert r["hist"].tolist() == hist.tolist()
         np.testing.assert_allclose(r["loss"], loss, rtol=1e-12, atol=1e-12)
     assert r0["loss"].tolist() == r1["loss"].tolist()   # every rank holds the identical combined vector
+    c0, c1 = np.load(tmp_path / "corpus0.npz"), np.load(tmp_path / "corpus1.npz")
+    assert np.array_equal(c0["data"], c1["data"]) and np.array_equal(c0["off"], c1["off"])
+    assert bool(c0["wrote"]) and not bool(c1["wrote"])

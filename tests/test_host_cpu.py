@@ -149,3 +149,84 @@ def test_partition_segments_balanced_and_whole():
         assert sum(sizes) == off[-1]
         if world > 1:
             assert max(sizes) <= off[-1] / world + (off[bounds[1:]] - off[bounds[:-1]]).max()
+
+
+def _load_corpus_fixture(tmp_path):
+    import hashlib
+    from sage_amd import synth
+    g = load_json_gz("load_corpus.json.gz")
+    a = g["corpus_args"]
+    corpus, _ = synth.make_corpus(a["n_lines"], seed=g["corpus_seed"], style=a["style"], n_types=a["n_types"],
+                                  mean_log_words=a["mean_log_words"], sigma_log_words=a["sigma_log_words"])
+    text = corpus.tobytes()[:-1]               # the last line has no newline
+    assert hashlib.sha256(text).hexdigest() == g["corpus_sha256"]
+    (tmp_path / "wiki.txt").write_bytes(text)
+    return g
+
+
+@pytest.mark.parametrize("packed", [True, False])
+def test_load_corpus_matches_reference_fixture(tmp_path, packed):
+    """utils.py:71-103 captured from the reference (tests/golden/make_golden.py load_corpus): same lines in the same
+    order under the same seed, file-identical partial corpus, same reload (where a line without a newline merges with
+    its successor) -- for the byte-buffer loader build_vocab uses and for the List[str] form."""
+    import hashlib
+    import random
+    from sage_amd import hostio, setSageFolder
+    g = _load_corpus_fixture(tmp_path)
+    for case in g["cases"]:
+        root = tmp_path / f"run_{case['seed']}_{packed}"
+        root.mkdir()
+        setSageFolder(root)
+        random.seed(case["seed"])
+        loader = hostio.load_corpus_packed if packed else hostio.load_corpus
+        got = loader(tmp_path / "wiki.txt", None, case["k"])
+        lines = [got[i] for i in range(len(got))]
+        assert lines == case["lines"]
+        saved = root / "data" / case["file_name"]
+        assert hashlib.sha256(saved.read_bytes()).hexdigest() == case["file_sha256"]
+        again = loader(tmp_path / "wiki.txt", saved, case["k"])
+        assert len(again) == case["reload_n"] and again[len(again) - 1] == case["reload_last"]
+        if packed:
+            assert int(got.offsets[-1]) == len(got.data) == sum(len(s.encode()) for s in case["lines"])
+
+
+def test_load_corpus_packed_translates_carriage_returns(tmp_path):
+    import random
+    from sage_amd import hostio, setSageFolder
+    setSageFolder(tmp_path)
+    (tmp_path / "c.txt").write_bytes(b"one\r\ntwo\rthree\nfour")
+    random.seed(1)
+    want = hostio.load_corpus(tmp_path / "c.txt", tmp_path / "p1.txt", 1)
+    random.seed(1)
+    got = hostio.load_corpus_packed(tmp_path / "c.txt", tmp_path / "p2.txt", 1)
+    assert [got[i] for i in range(len(got))] == want and sorted(want) == ["four", "one\n", "three\n", "two\n"]
+    assert (tmp_path / "p1.txt").read_bytes() == (tmp_path / "p2.txt").read_bytes()
+    empty = tmp_path / "empty.txt"
+    empty.write_bytes(b"")
+    assert len(hostio.load_corpus_packed(empty, tmp_path / "p3.txt", 1)) == 0
+
+
+def test_near_ties_at_cut():
+    from sage_amd.builder import near_ties_at_cut
+    ranked = sorted([(-5.0, 1), (-3.0, 2), (-3.0 + 1e-12, 3), (-3.0 + 2e-12, 7), (-1.0, 4), (0.5, 5), (1e6, 0)])
+    assert near_ties_at_cut(ranked, 1) == ([], [])                       # -5 | -3: clear
+    low, high = near_ties_at_cut(ranked, 2)                               # -3 | -3+1e-12: a near-tie
+    assert low == [(-3.0, 2)] and high == [(-3.0 + 1e-12, 3), (-3.0 + 2e-12, 7)]
+    low, high = near_ties_at_cut(ranked, 3)
+    assert [t for _, t in low] == [2, 3] and [t for _, t in high] == [7]
+    assert near_ties_at_cut(ranked, 4) == ([], []) and near_ties_at_cut(ranked, 0) == ([], [])
+    assert near_ties_at_cut(ranked, len(ranked)) == ([], [])
+    exact = sorted([(-2.0, 9), (-2.0, 3), (4.0, 1)])
+    assert near_ties_at_cut(exact, 1) == ([(-2.0, 3)], [(-2.0, 9)])      # exact tie: the id decides, still reported
+
+
+def test_packed_corpus_behaves_like_a_list_of_lines():
+    from sage_amd.parallel import PackedCorpus, pack_lines
+    lines = ["ab\n", "çd e\n", "last"]
+    flat, off = pack_lines(lines)
+    pc = PackedCorpus(flat, off)
+    assert len(pc) == 3 and [pc[i] for i in range(3)] == lines and pc[-1] == "last"
+    sub = pc[1:3]
+    assert isinstance(sub, PackedCorpus) and [sub[i] for i in range(len(sub))] == lines[1:3]
+    assert pc[::2] == lines[::2]
+    assert pc.line_bytes(1) == "çd e\n".encode()
