@@ -151,9 +151,10 @@ def test_keys_longer_than_max_len_are_ignored_not_refused():
     corpus, off = synth.make_corpus(80, seed=4, n_types=600, mean_log_words=2.3)
     vocab = synth.make_vocab(corpus, off, 700, 20, sample_bytes=60_000)
     lines = synth.corpus_lines(corpus, off)
-    long_key = lines[0].encode()[:40]
-    vocab = vocab[:300] + [long_key, b" " * 64] + vocab[300:]
-    assert max(len(v) for v in vocab) == 64 and sum(len(v) > 12 for v in vocab) > 2
+    # keys that DO occur in the text (line starts) but are longer than max_len = 12, one beyond the 32-byte table limit
+    extra = [lines[0].encode()[:40], lines[1].encode()[:14], lines[2].encode()[:16], lines[3].encode()[:13], b" " * 64]
+    vocab = vocab[:300] + [k for k in extra if k not in vocab] + vocab[300:]
+    assert max(len(v) for v in vocab) == 64 and sum(len(v) > 12 for v in vocab) >= 5
     model = SaGeTokenizer(vocab, 12)
     emb = synth.make_embeddings(len(vocab), 50, seed=2)
     tt, ttr, losses, sizes = run_sage_parallel(emb, lines, model, 2)
