@@ -79,6 +79,26 @@ int sage_tokenize(sage_ctx* ctx, int64_t line_begin, int64_t line_end, int32_t* 
                   int32_t* out_widths, int64_t capacity, int64_t* out_counts, int64_t* out_total);
 
 /*
+ * Allocation-free tokenization.  NO COUNTERPART IN THE REFERENCE: a variant of sage_tokenize for callers that cannot
+ * allocate device memory at the point of the call -- code under HIP graph capture, tight serving loops that tokenize
+ * request batches with the resident vocabulary, harnesses that forbid hipMalloc.  The call allocates and frees no
+ * device memory: its scratch (text copy with its zero pad, line remainders, the match table, per-line counters)
+ * lives in a static device array of ~10.6 MiB that every GPU the library runs on holds until the process ends.
+ * Inputs and outputs are the CALLER's DEVICE buffers: d_text[n_bytes] holds the lines back to back, d_line_offsets
+ * [n_lines + 1] their byte offsets (int64, from 0 to n_bytes); d_ids/d_starts/d_widths[capacity] (all three or none)
+ * and d_counts[n_lines] (optional) receive what sage_tokenize returns; *out_total (host) = number of tokens.  The
+ * vocabulary is the one sage_set_vocab uploaded; no corpus needs to be resident and a resident one is left alone.
+ * Limits: n_bytes <= SAGE_NOALLOC_MAX_BYTES and n_lines <= SAGE_NOALLOC_MAX_LINES per call (SAGE_E_LIMIT beyond).
+ * All calls on one GPU share that GPU's scratch array: calls that overlap in time on one GPU (two contexts, two
+ * threads) race -- serialise them.  The call returns after the context's stream has been synchronised.
+ */
+#define SAGE_NOALLOC_MAX_BYTES (1 << 20)
+#define SAGE_NOALLOC_MAX_LINES (1 << 16)
+int sage_tokenize_noalloc(sage_ctx* ctx, const uint8_t* d_text, int64_t n_bytes, const int64_t* d_line_offsets,
+                          int64_t n_lines, int32_t* d_ids, int32_t* d_starts, int32_t* d_widths, int64_t capacity,
+                          int64_t* d_counts, int64_t* out_total);
+
+/*
  * One ablation step: replaces run_sage_parallel -> sage_per_chunk -> fast_sage/do_triples/compute_losses
  * (utils.py:141-257, model.py:115-248) over the lines [segment_line_bounds[0], segment_line_bounds[n_segments]).
  * segment_line_bounds has n_segments+1 increasing line indices; each [b[s], b[s+1]) is one range over which

@@ -53,6 +53,8 @@ def load():
     lib.sage_set_embeddings.argtypes = [vp, pf64, i64, i32]
     lib.sage_tokenize.restype = C.c_int
     lib.sage_tokenize.argtypes = [vp, i64, i64, pi32, pi32, pi32, i64, pi64, pi64]
+    lib.sage_tokenize_noalloc.restype = C.c_int
+    lib.sage_tokenize_noalloc.argtypes = [vp, vp, i64, vp, i64, vp, vp, vp, i64, vp, pi64]
     lib.sage_ablation_step.restype = C.c_int
     lib.sage_ablation_step.argtypes = [vp, pi64, i64, i32, pf64, pi64, i64, pi64, pi64, pi64, i64]
     lib.sage_ablation_step_device.restype = C.c_int
@@ -81,7 +83,7 @@ def load():
 
 
 EXPORTED = ["sage_version", "sage_create", "sage_destroy", "sage_last_error", "sage_set_vocab", "sage_set_corpus",
-            "sage_set_embeddings", "sage_tokenize", "sage_ablation_step", "sage_ablation_step_device",
+            "sage_set_embeddings", "sage_tokenize", "sage_tokenize_noalloc", "sage_ablation_step", "sage_ablation_step_device",
             "sage_set_profiling", "sage_reset_kernel_times", "sage_get_kernel_times", "sage_set_batch_bytes",
             "sage_set_match_mode", "sage_set_count_mode", "sage_set_score_mode", "sage_train_embeddings", "sage_get_step_stats"]
 
@@ -171,6 +173,20 @@ class HipSage:
         self._check(self._lib.sage_tokenize(self._h, line_begin, line_end, _ptr(ids, C.c_int32), _ptr(starts, C.c_int32),
                                             _ptr(widths, C.c_int32), total, _ptr(counts, C.c_int64), C.byref(tot2)))
         return ids[:total], starts[:total], widths[:total], counts
+
+    NOALLOC_MAX_BYTES = 1 << 20
+    NOALLOC_MAX_LINES = 1 << 16
+
+    def tokenize_noalloc(self, d_text: int, n_bytes: int, d_line_offsets: int, n_lines: int, d_ids: int = 0,
+                         d_starts: int = 0, d_widths: int = 0, capacity: int = 0, d_counts: int = 0) -> int:
+        """sage_tokenize_noalloc: device buffers given as raw addresses (e.g. torch.Tensor.data_ptr()); allocates no
+        device memory.  Returns the number of tokens."""
+        total = C.c_int64(0)
+        p = lambda a: C.c_void_p(a) if a else None
+        self._check(self._lib.sage_tokenize_noalloc(self._h, p(d_text), int(n_bytes), p(d_line_offsets), int(n_lines),
+                                                    p(d_ids), p(d_starts), p(d_widths), int(capacity), p(d_counts),
+                                                    C.byref(total)))
+        return total.value
 
     def ablation_step(self, segment_line_bounds, pad: int = 2, vsize: int | None = None):
         """-> (loss f64[vsize], occ i64[vsize], total_tokens, total_triples, hist i64[self.hist_len])."""

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <atomic>
@@ -33,8 +34,28 @@ struct EventPair { hipEvent_t a, b; int cls; };
 
 }  // namespace
 
+// ---- scratch of the allocation-free entry point (sage_tokenize_noalloc) ---------------------------------------------
+// One file-scope device array per GPU the library runs on, held until the process ends.  Its NAME is a host-side
+// stand-in, not a device address: host code only ever uses the per-device pointer hipGetSymbolAddress returns
+// (scratch_for_device below), as kernel argument and for memsets and copies alike.
+constexpr size_t NA_ALIGN = 256;
+constexpr size_t na_up(size_t x) { return (x + NA_ALIGN - 1) / NA_ALIGN * NA_ALIGN; }
+constexpr size_t NA_TEXT = 0;                                                          // text + 1 KiB zero pad
+constexpr size_t NA_REM = NA_TEXT + na_up(SAGE_NOALLOC_MAX_BYTES + 1024);              // bytes to the line end
+constexpr size_t NA_M = NA_REM + na_up(SAGE_NOALLOC_MAX_BYTES + 1024);                 // match table, 8 B per byte
+constexpr size_t NA_NTOK = NA_M + na_up((size_t)SAGE_NOALLOC_MAX_BYTES * 8);
+constexpr size_t NA_NOCC = NA_NTOK + na_up((size_t)SAGE_NOALLOC_MAX_LINES * 4);
+constexpr size_t NA_TOKOFF = NA_NOCC + na_up((size_t)SAGE_NOALLOC_MAX_LINES * 4);
+constexpr size_t NA_OCCOFF = NA_TOKOFF + na_up(((size_t)SAGE_NOALLOC_MAX_LINES + 1) * 4);
+constexpr size_t NA_TILES = NA_OCCOFF + na_up(((size_t)SAGE_NOALLOC_MAX_LINES + 1) * 4);
+constexpr size_t NA_TOTAL = NA_TILES + na_up(((size_t)SAGE_NOALLOC_MAX_LINES / SCAN_TILE + 2) * 4);
+constexpr size_t NA_FLAGS = NA_TOTAL + na_up(16);
+constexpr size_t NA_BYTES = NA_FLAGS + na_up(FLAG_COUNT * 4);                           // ~10.6 MiB
+static __device__ __align__(256) unsigned char scratch[NA_BYTES];
+
 struct sage_ctx {
     int device = 0;
+    unsigned char* na_scratch = nullptr;   // this device's copy of `scratch` (hipGetSymbolAddress at sage_create)
     int n_cu = 256;
     hipStream_t stream = nullptr;
     std::string err;
@@ -93,6 +114,24 @@ namespace {
 int fail(sage_ctx* c, int code, const std::string& msg) {
     if (c) c->err = msg;
     return code;
+}
+
+// Device address of this GPU's `scratch` array; looked up once per device, with that device current.
+constexpr int NA_MAX_DEVICES = 64;
+std::mutex g_na_mutex;
+unsigned char* g_na_ptr[NA_MAX_DEVICES] = {nullptr};
+hipError_t scratch_for_device(int device, unsigned char** out) {
+    if (device < 0 || device >= NA_MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_na_mutex);
+    if (!g_na_ptr[device]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));   // resolves for the CURRENT device
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        g_na_ptr[device] = static_cast<unsigned char*>(p);
+    }
+    *out = g_na_ptr[device];
+    return hipSuccess;
 }
 
 #define HIP_TRY(c, expr)                                                                                   \
@@ -159,19 +198,71 @@ uint64_t pow2ceil(uint64_t x) {
 inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
 // exclusive scan of n u32 values: out has n+1 entries, *total (device u64) gets the grand total
-int scan_u32(sage_ctx* c, const uint32_t* in, uint32_t n, uint32_t* out, uint64_t* d_total) {
-    const uint32_t n_tiles = std::max(1u, cdiv(n, SCAN_TILE));
-    int rc;
-    if ((rc = ensure(c, c->tile_sums, (size_t)n_tiles * 4))) return rc;
+inline uint32_t scan_tiles(uint32_t n) { return std::max(1u, cdiv(n, SCAN_TILE)); }
+
+// the three scan kernels with the tile-sum buffer given (scan_tiles(n) words)
+void scan_u32_with(sage_ctx* c, const uint32_t* in, uint32_t n, uint32_t* out, uint64_t* d_total, uint32_t* tile_sums) {
+    const uint32_t n_tiles = scan_tiles(n);
     Prof p(c, SAGE_K_SCAN);
-    k_scan_tile_sums<<<n_tiles, 256, 0, c->stream>>>(in, n, c->tile_sums.as<uint32_t>());
-    k_scan_top<<<1, 256, 0, c->stream>>>(c->tile_sums.as<uint32_t>(), n_tiles, d_total);
-    k_scan_apply<<<n_tiles, 256, 0, c->stream>>>(in, n, c->tile_sums.as<uint32_t>(), out);
+    k_scan_tile_sums<<<n_tiles, 256, 0, c->stream>>>(in, n, tile_sums);
+    k_scan_top<<<1, 256, 0, c->stream>>>(tile_sums, n_tiles, d_total);
+    k_scan_apply<<<n_tiles, 256, 0, c->stream>>>(in, n, tile_sums, out);
+}
+
+int scan_u32(sage_ctx* c, const uint32_t* in, uint32_t n, uint32_t* out, uint64_t* d_total) {
+    int rc;
+    if ((rc = ensure(c, c->tile_sums, (size_t)scan_tiles(n) * 4))) return rc;
+    scan_u32_with(c, in, n, out, d_total, c->tile_sums.as<uint32_t>());
     return SAGE_OK;
 }
 
-// K1 + K2a(count) + scans over lines [line0, line1): fills M, ntok/tokoff and nocc/occoff;
-// grand_total[0] = tokens, grand_total[1] = ablated occurrences (device).  out_total (optional) syncs.
+// Buffers of the matcher + base walk: the context's grow-only allocations (match_and_count) or pieces of the static
+// scratch array (sage_tokenize_noalloc).
+struct MatchBufs {
+    const uint8_t* corpus;      // text, readable up to 1 KiB past its last byte
+    const uint8_t* rem;         // bytes to the line end per text byte
+    const int64_t* line_off;    // device line offsets, indexed from line 0 of `corpus`
+    uint2* M;                   // [nb]
+    uint32_t *ntok, *nocc;      // [nl]
+    uint32_t *tokoff, *occoff;  // [nl + 1]
+    uint32_t* tile_sums;        // [scan_tiles(nl)]
+    uint64_t* grand_total;      // [2]
+    uint32_t* flags;            // [FLAG_COUNT]
+};
+
+// K1 + K2a(count) + scans over the nl lines from line0 (nb text bytes from pos0): fills M, ntok/tokoff and nocc/occoff;
+// grand_total[0] = tokens, grand_total[1] = ablated occurrences (device).  Launches only: nothing is allocated.
+void launch_match_and_count(sage_ctx* c, const MatchBufs& B, int64_t line0, uint32_t nl, int64_t pos0, uint64_t nb) {
+    VocabDev v{c->buckets.as<uint4>(), c->bucket_mask, c->keys.as<uint64_t>(), c->key_plane, c->byte_id.as<uint32_t>(),
+               c->direct2.as<uint32_t>(), c->bloom.as<uint32_t>(), c->pmask.p, c->pmask8.p, c->max_len};
+    if (nb) {
+        Prof p(c, SAGE_K_MATCH);
+        const uint32_t grid = cdiv(nb, 256);
+        const int nw = (c->max_len + 7) / 8;
+        if (c->match_mode == 0) {
+            const uint32_t pgrid = std::min<uint32_t>(cdiv(nb, 1024), (uint32_t)c->n_cu);
+            switch (nw) {
+            case 1: k_match_lds<1><<<pgrid, 1024, 0, c->stream>>>(B.corpus, B.rem, pos0, (uint32_t)nb, v, B.M); break;
+            case 2: k_match_lds<2><<<pgrid, 1024, 0, c->stream>>>(B.corpus, B.rem, pos0, (uint32_t)nb, v, B.M); break;
+            case 3: k_match_lds<3><<<pgrid, 1024, 0, c->stream>>>(B.corpus, B.rem, pos0, (uint32_t)nb, v, B.M); break;
+            default: k_match_lds<4><<<pgrid, 1024, 0, c->stream>>>(B.corpus, B.rem, pos0, (uint32_t)nb, v, B.M); break;
+            }
+        } else switch (nw) {
+        case 1: k_match<1><<<grid, 256, 0, c->stream>>>(B.corpus, B.rem, pos0, (uint32_t)nb, v, B.M); break;
+        case 2: k_match<2><<<grid, 256, 0, c->stream>>>(B.corpus, B.rem, pos0, (uint32_t)nb, v, B.M); break;
+        case 3: k_match<3><<<grid, 256, 0, c->stream>>>(B.corpus, B.rem, pos0, (uint32_t)nb, v, B.M); break;
+        default: k_match<4><<<grid, 256, 0, c->stream>>>(B.corpus, B.rem, pos0, (uint32_t)nb, v, B.M); break;
+        }
+    }
+    {
+        Prof p(c, SAGE_K_WALK);
+        k_walk_count<<<cdiv(nl, 256), 256, 0, c->stream>>>(B.line_off, line0, nl, pos0, B.M, B.ntok, B.nocc, B.flags);
+    }
+    scan_u32_with(c, B.ntok, nl, B.tokoff, B.grand_total, B.tile_sums);
+    scan_u32_with(c, B.nocc, nl, B.occoff, B.grand_total + 1, B.tile_sums);
+}
+
+// The same over lines [line0, line1) of the resident corpus, into the context's buffers.  out_total (optional) syncs.
 int match_and_count(sage_ctx* c, int64_t line0, int64_t line1, uint64_t* out_total) {
     const int64_t pos0 = c->h_line_off[line0];
     const uint64_t nb = (uint64_t)(c->h_line_off[line1] - pos0);
@@ -184,39 +275,11 @@ int match_and_count(sage_ctx* c, int64_t line0, int64_t line1, uint64_t* out_tot
     if ((rc = ensure(c, c->tokoff, ((size_t)nl + 1) * 4))) return rc;
     if ((rc = ensure(c, c->occoff, ((size_t)nl + 1) * 4))) return rc;
     if ((rc = ensure(c, c->grand_total, 16))) return rc;
-
-    VocabDev v{c->buckets.as<uint4>(), c->bucket_mask, c->keys.as<uint64_t>(), c->key_plane, c->byte_id.as<uint32_t>(),
-               c->direct2.as<uint32_t>(), c->bloom.as<uint32_t>(), c->pmask.p, c->pmask8.p, c->max_len};
-    if (nb) {
-        Prof p(c, SAGE_K_MATCH);
-        const uint32_t grid = cdiv(nb, 256);
-        const int nw = (c->max_len + 7) / 8;
-        const uint8_t* corpus = c->corpus.as<uint8_t>();
-        const uint8_t* rem = c->rem.as<uint8_t>();
-        uint2* M = c->M.as<uint2>();
-        if (c->match_mode == 0) {
-            const uint32_t pgrid = std::min<uint32_t>(cdiv(nb, 1024), (uint32_t)c->n_cu);
-            switch (nw) {
-            case 1: k_match_lds<1><<<pgrid, 1024, 0, c->stream>>>(corpus, rem, pos0, (uint32_t)nb, v, M); break;
-            case 2: k_match_lds<2><<<pgrid, 1024, 0, c->stream>>>(corpus, rem, pos0, (uint32_t)nb, v, M); break;
-            case 3: k_match_lds<3><<<pgrid, 1024, 0, c->stream>>>(corpus, rem, pos0, (uint32_t)nb, v, M); break;
-            default: k_match_lds<4><<<pgrid, 1024, 0, c->stream>>>(corpus, rem, pos0, (uint32_t)nb, v, M); break;
-            }
-        } else switch (nw) {
-        case 1: k_match<1><<<grid, 256, 0, c->stream>>>(corpus, rem, pos0, (uint32_t)nb, v, M); break;
-        case 2: k_match<2><<<grid, 256, 0, c->stream>>>(corpus, rem, pos0, (uint32_t)nb, v, M); break;
-        case 3: k_match<3><<<grid, 256, 0, c->stream>>>(corpus, rem, pos0, (uint32_t)nb, v, M); break;
-        default: k_match<4><<<grid, 256, 0, c->stream>>>(corpus, rem, pos0, (uint32_t)nb, v, M); break;
-        }
-    }
-    {
-        Prof p(c, SAGE_K_WALK);
-        k_walk_count<<<cdiv(nl, 256), 256, 0, c->stream>>>(c->line_off.as<int64_t>(), line0, nl, pos0,
-                                                            c->M.as<uint2>(), c->ntok.as<uint32_t>(),
-                                                            c->nocc.as<uint32_t>(), c->flags.as<uint32_t>());
-    }
-    if ((rc = scan_u32(c, c->ntok.as<uint32_t>(), nl, c->tokoff.as<uint32_t>(), c->grand_total.as<uint64_t>()))) return rc;
-    if ((rc = scan_u32(c, c->nocc.as<uint32_t>(), nl, c->occoff.as<uint32_t>(), c->grand_total.as<uint64_t>() + 1))) return rc;
+    if ((rc = ensure(c, c->tile_sums, (size_t)scan_tiles(nl) * 4))) return rc;
+    const MatchBufs B{c->corpus.as<uint8_t>(), c->rem.as<uint8_t>(), c->line_off.as<int64_t>(), c->M.as<uint2>(),
+                      c->ntok.as<uint32_t>(), c->nocc.as<uint32_t>(), c->tokoff.as<uint32_t>(), c->occoff.as<uint32_t>(),
+                      c->tile_sums.as<uint32_t>(), c->grand_total.as<uint64_t>(), c->flags.as<uint32_t>()};
+    launch_match_and_count(c, B, line0, nl, pos0, nb);
     HIP_TRY(c, hipGetLastError());
     if (out_total) {
         uint64_t tot = 0;
@@ -614,6 +677,7 @@ int sage_create(int device, sage_ctx** out_ctx) {
     }
     // test hook: start with a smaller id pool so that the overflow-and-redo path can be exercised
     if (const char* e = std::getenv("SAGE_POOL_FACTOR")) { const int v = std::atoi(e); if (v >= 0 && v <= 64) c->pool_factor = v; }
+    if (scratch_for_device(device, &c->na_scratch) != hipSuccess) { delete c; return SAGE_E_HIP; }   // device is current
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SAGE_E_HIP; }
     if (hipMalloc(&c->flags.p, FLAG_COUNT * 4) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return SAGE_E_HIP; }
     c->flags.cap = FLAG_COUNT * 4;
@@ -1014,6 +1078,66 @@ int sage_tokenize(sage_ctx* c, int64_t line_begin, int64_t line_end, int32_t* ou
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     collect_events(c);
     if (out_total) *out_total = total;
+    return SAGE_OK;
+}
+
+int sage_tokenize_noalloc(sage_ctx* c, const uint8_t* d_text, int64_t n_bytes, const int64_t* d_line_offsets,
+                          int64_t n_lines, int32_t* d_ids, int32_t* d_starts, int32_t* d_widths, int64_t capacity,
+                          int64_t* d_counts, int64_t* out_total) {
+    if (!c) return SAGE_E_ARG;
+    if (!c->have_vocab) return fail(c, SAGE_E_STATE, "sage_set_vocab has not been called");
+    if (!d_line_offsets || n_lines < 0 || n_bytes < 0 || (n_bytes > 0 && !d_text) || capacity < 0)
+        return fail(c, SAGE_E_ARG, "bad argument");
+    const bool want_tokens = d_ids || d_starts || d_widths;
+    if (want_tokens && !(d_ids && d_starts && d_widths)) return fail(c, SAGE_E_ARG, "pass all three token arrays or none");
+    if (n_bytes > SAGE_NOALLOC_MAX_BYTES)
+        return fail(c, SAGE_E_LIMIT, "sage_tokenize_noalloc takes at most SAGE_NOALLOC_MAX_BYTES (1 MiB) of text per call");
+    if (n_lines > SAGE_NOALLOC_MAX_LINES)
+        return fail(c, SAGE_E_LIMIT, "sage_tokenize_noalloc takes at most SAGE_NOALLOC_MAX_LINES (65,536) lines per call");
+    if (!c->na_scratch) return fail(c, SAGE_E_STATE, "the scratch array was not resolved for this device");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (out_total) *out_total = 0;
+    if (n_lines == 0) return SAGE_OK;
+    // the kernels trust the line offsets: check them on the host first (host memory only; <= 512 KiB)
+    std::vector<int64_t> off((size_t)n_lines + 1);
+    HIP_TRY(c, hipMemcpyAsync(off.data(), d_line_offsets, off.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (off[0] != 0 || off[(size_t)n_lines] != n_bytes) return fail(c, SAGE_E_ARG, "line offsets must run from 0 to n_bytes");
+    for (int64_t i = 0; i < n_lines; ++i)
+        if (off[(size_t)i + 1] < off[(size_t)i]) return fail(c, SAGE_E_ARG, "line_offsets must be non-decreasing");
+
+    unsigned char* S = c->na_scratch;          // never the array's name: see the note at its definition
+    uint8_t* text = S + NA_TEXT;
+    uint8_t* rem = S + NA_REM;
+    const MatchBufs B{text, rem, d_line_offsets, reinterpret_cast<uint2*>(S + NA_M),
+                      reinterpret_cast<uint32_t*>(S + NA_NTOK), reinterpret_cast<uint32_t*>(S + NA_NOCC),
+                      reinterpret_cast<uint32_t*>(S + NA_TOKOFF), reinterpret_cast<uint32_t*>(S + NA_OCCOFF),
+                      reinterpret_cast<uint32_t*>(S + NA_TILES), reinterpret_cast<uint64_t*>(S + NA_TOTAL),
+                      reinterpret_cast<uint32_t*>(S + NA_FLAGS)};
+    const uint32_t nl = (uint32_t)n_lines;
+    // the array keeps the last call's contents: what must start at zero is cleared here (the text's pad, which the
+    // matcher's 64-byte tiles read past the last byte, the totals and the flags); everything else is written before
+    // it is read.  The text is copied in because the caller's buffer has no such pad.
+    if (n_bytes) HIP_TRY(c, hipMemcpyAsync(text, d_text, (size_t)n_bytes, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(text + n_bytes, 0, 1024, c->stream));
+    HIP_TRY(c, hipMemsetAsync(S + NA_TOTAL, 0, 16, c->stream));
+    HIP_TRY(c, hipMemsetAsync(S + NA_FLAGS, 0, FLAG_COUNT * 4, c->stream));
+    if (n_bytes)
+        k_line_remaining<<<cdiv((uint64_t)n_bytes, 256), 256, 0, c->stream>>>(d_line_offsets, n_lines, rem, n_bytes);
+    launch_match_and_count(c, B, 0, nl, 0, (uint64_t)n_bytes);
+    HIP_TRY(c, hipGetLastError());
+    uint64_t total = 0;
+    HIP_TRY(c, hipMemcpyAsync(&total, B.grand_total, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (d_counts) k_widen_counts<<<cdiv(nl, 256), 256, 0, c->stream>>>(B.ntok, nl, d_counts);
+    if (want_tokens && total) {
+        if ((int64_t)total > capacity) return fail(c, SAGE_E_ARG, "token capacity too small");
+        k_walk_write<true><<<cdiv(nl, 256), 256, 0, c->stream>>>(d_line_offsets, 0, nl, 0, B.M, B.tokoff, nullptr, nullptr,
+                                                                nullptr, nullptr, d_ids, d_starts, d_widths);
+    }
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (out_total) *out_total = (int64_t)total;
     return SAGE_OK;
 }
 

@@ -595,6 +595,11 @@ __global__ void k_gather_u32(const uint32_t* __restrict__ src, const uint32_t* _
     if (i < n) dst[i] = src[idx[i]];
 }
 
+__global__ void k_widen_counts(const uint32_t* __restrict__ src, uint32_t n, int64_t* __restrict__ dst) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = (int64_t)src[i];
+}
+
 // What the ablation walk (walk_occurrence, sage_kernels2.h) reads: the match table M and the compact token arrays.
 struct WalkArrays {
     const uint2* M;
