@@ -5,12 +5,21 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path (greedy tokenization + ablation counts + f64 scoring, i.e. one
-run_sage_parallel call, utils.py:141-257) over the rank's resident corpus shard.  Workload at N=1: the 1M-line
+A "step" is one pass of the hot path (greedy tokenization + ablation counts + f64 scoring, i.e. the device work of
+one run_sage_parallel call, utils.py:141-257) over the rank's resident corpus shard.  Workload at N=1: the 1M-line
 synthetic English-Wikipedia-shaped corpus with a 262,144-key vocabulary (BASELINE.json configs[1]); at N>1 every
 rank holds its own 1M-line shard (weak scaling) and the per-step result vectors (loss f64[V], occurrences
-i64[V], histogram, totals) are combined over RCCL.  Corpus, vocabulary and embeddings are uploaded before the
-timed region; the timed region is K steps between barrier + synchronize pairs; rank 0 prints ONE JSON line.
+i64[V], histogram, totals) are combined over RCCL by the product's own `sage_amd.dist.step_into`.  Corpus,
+vocabulary and embeddings are uploaded before the timed region; the timed region is K steps between barrier +
+synchronize pairs; rank 0 prints ONE JSON line.
+
+Besides `value` the line carries
+  run_sage_parallel_ms  what SURVEY.md 8d names: one whole `sage_amd.parallel.run_sage_parallel` call right after a
+                        `set_vocabulary` (vocabulary re-upload + step + result dicts), N=1 only;
+  roofline              the dominant kernel: algorithmic bytes per launch (formulas below and in DESIGN.md) over its
+                        average launch time from HIP events on the library's stream;
+  step_roofline         the whole step against SURVEY.md 8d's bytes per token, with e = 4 (what is stored) and e = 8;
+  cpu_baseline          the oracle port on this host's cores, on a bounded sample of the same corpus.
 """
 from __future__ import annotations
 
@@ -29,27 +38,33 @@ sys.path.insert(0, str(REPO))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # kernel class (sage_hip.h SAGE_K_*) -> the kernel that dominates it in the rocprofv3 traces under profiles/
-CLASS_KERNEL = {"match": "k_match_lds", "score": "k_dots", "count": "k_key_dedupe", "partition": "k_key_partition<1>", "describe": "k_describe",
-                "pairs": "k_pair_cache", "logsig": "k_logsig", "walk": "k_walk_write"}
+CLASS_KERNEL = {"match": "k_match_lds", "score": "k_dots", "count": "k_key_dedupe", "partition": "k_key_partition<1>",
+                "describe": "k_describe<false>", "pairs": "k_pair_cache", "logsig": "k_logsig", "walk": "k_walk_write"}
+# what bounds each kernel class (Kernels): only the "hbm" ones stream HBM; the HBM peak is quoted for all
+CLASS_BOUND = {"match": "valu-issue", "score": "l2-fabric-gather", "pairs": "l2-fabric-gather", "fix": "l2-fabric-gather",
+               "count": "hbm", "partition": "hbm", "describe": "lds-latency", "logsig": "hbm", "walk": "latency"}
 
 
 def pmc_traffic(kernel_class, args):
-    """HBM-side bytes per launch of the dominant kernel, from the committed PMC passes (profiles/collect.sh:
-    FETCH_SIZE and WRITE_SIZE in runs of their own; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
-    16-B-per-lane reads on gfx950).  Only valid for the default workload the passes were taken on; else None."""
+    """HBM-side bytes per launch of a kernel from the newest committed PMC passes (profiles/collect.sh: FETCH_SIZE and
+    WRITE_SIZE in runs of their own): raw, with FETCH_SIZE doubled (MI355X_MICROARCH.md: right for 16-B-per-lane
+    streaming reads) and with the factor profiles/*_pmc_calibration.json measured for the kernel's own access shape.
+    Only valid for the default workload the passes were taken on; else None."""
     if (args.lines, args.vocab, args.dim, args.max_len, args.style) != (1_000_000, 262_144, 50, 16, "en"):
         return None
-    def version_key(path):   # r01_v13 after r01_v9: numbers compared as numbers
+    def version_key(path):   # r02_v3 after r01_v15: numbers compared as numbers
         return [int(x) for x in re.findall(r"\d+", path.name)]
     files = sorted((REPO / "profiles").glob("r*_pmc_traffic.json"), key=version_key)
     if not files:
         return None
-    want = CLASS_KERNEL.get(kernel_class)
-    if kernel_class == "__step_total__":
-        want = "__step_total__"
+    want = "__step_total__" if kernel_class == "__step_total__" else CLASS_KERNEL.get(kernel_class)
     for row in json.loads(files[-1].read_text()):
         if want and row["kernel"].startswith(want):
-            return (row["fetch_x2_GB_per_launch"] + row["write_GB_per_launch"]) * 1e9
+            out = {"source": files[-1].name, "raw": (row["fetch_GB_per_launch"] + row["write_GB_per_launch"]) * 1e9,
+                   "fetch_x2": (row["fetch_x2_GB_per_launch"] + row["write_GB_per_launch"]) * 1e9}
+            if "calibrated_GB_per_launch" in row:
+                out["calibrated"] = row["calibrated_GB_per_launch"] * 1e9
+            return out
     return None
 
 
@@ -68,6 +83,7 @@ def parse():
     ap.add_argument("--batch-mb", type=int, default=0)
     ap.add_argument("--score-mode", type=int, default=0, help="0 = float32 row storage where lossless, 1 = float64 storage")
     ap.add_argument("--match-mode", type=int, default=-1, help="matcher variant (development switch)")
+    ap.add_argument("--no-api-timing", action="store_true", help="skip the run_sage_parallel_ms measurement")
     return ap.parse_args()
 
 
@@ -95,6 +111,24 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
+def algorithmic_bytes(st, dim):
+    """Per step and rank, per kernel class: the bytes the algorithm has to move (Kernels, states each).
+    e = bytes per stored embedding element on the main pass (4: the lossless float32 copy)."""
+    e = st["emb_elem_bytes"]
+    tok, occ, nb = st["tokens"], st["occurrences"], st["corpus_bytes"]
+    return {
+        "match": nb * (1 + 1 + 8),                              # text + rem read, 8-byte match entry written, per byte
+        "walk": tok * 8 * 2 + tok * 12,                         # M entry of every token read by both passes; token arrays out
+        "describe": st["rows"] * 8 + occ * 64,                  # 8 B of M per window/span element, 64-byte descriptor out
+        "partition": occ * 64 + st["pairs"] * 8,                # descriptors in, one 8-byte record per position pair out
+        "count": st["pairs"] * 8,                               # every record read once
+        "pairs": tok * (dim * e + 16),                          # one row per token, 16-byte pair-cache entry out
+        "score": st["window_rows"] * dim * e + occ * 64,        # the rows of the ablated windows only + descriptors
+        "logsig": st["window_pairs"] * 8 + occ * (16 + 32),     # dots read once; header + pair-cache window per occurrence
+        "fix": st["f64_fix_occurrences"] * (st["window_rows"] / max(1, occ) * dim * 8 + 64),
+    }
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -102,7 +136,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     # SAGE_BENCH_REHEARSE=1: run the N>1 code path on a ONE-GPU box (every rank on cuda:0, gloo, collectives staged
-    # through host memory).  For checking the multi-rank flow only; its numbers mean nothing.
+    # through host memory by sage_amd.dist).  For checking the multi-rank flow only; its numbers mean nothing.
     rehearse = os.environ.get("SAGE_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = 0
@@ -115,13 +149,12 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    def all_reduce_(t, op=None):
-        from sage_amd.dist import _through_host
-        _through_host(dist, t, lambda x: dist.all_reduce(x, op=op or dist.ReduceOp.SUM))
+    from sage_amd import SaGeTokenizer, parallel, synth
+    from sage_amd.dist import StepBuffers, _through_host, step_into
+    from sage_amd.parallel import PackedCorpus, segment_line_bounds
 
-    from sage_amd import synth
-    from sage_amd._lib import HipSage
-    from sage_amd.parallel import segment_line_bounds
+    def all_reduce_(t, op=None):
+        _through_host(dist, t, lambda x: dist.all_reduce(x, op=op or dist.ReduceOp.SUM))
 
     seed = synth.DEFAULT_SEED
     t_gen = time.time()
@@ -140,19 +173,22 @@ def main():
     log(f"corpus: {len(corpus)} bytes")
     gen_s = time.time() - t_gen
 
-    eng = HipSage(local_rank)
+    # the product's own objects: tokenizer state on the host, packed corpus, one engine per GPU
+    model = SaGeTokenizer(vocab, args.max_len)
+    packed = PackedCorpus(corpus, offsets)
+    eng = parallel.get_engine(local_rank)
     if args.batch_mb:
         eng.set_batch_bytes(args.batch_mb << 20)
     if args.match_mode >= 0:
         eng.set_match_mode(args.match_mode)
     eng.set_score_mode(args.score_mode)
     t_up = time.time()
-    eng.set_vocab(vocab, None, args.max_len)
+    parallel.sync_vocab(eng, model)
+    parallel.sync_corpus(eng, packed)
     # Embeddings as train_embeddings leaves them (embeddings.py:77-89): float32 word2vec vectors for the tokens the
     # tokenized corpus contains (word2vec is trained on that very tokenization, min_count=1), the float64 uniform
     # draw for the rest.  The corpus is tokenized here on the GPU; with several ranks the token counts are summed so
     # that every rank builds the same matrix.
-    eng.set_corpus(corpus, offsets)
     seen_counts = np.bincount(eng.tokenize(0, len(offsets) - 1)[0], minlength=len(vocab)).astype(np.int64)
     if world > 1:
         t = torch.from_numpy(seen_counts).cuda()
@@ -161,19 +197,14 @@ def main():
     seen = seen_counts > 0
     emb = synth.make_embeddings(len(vocab), args.dim, seed=seed, unseen=~seen)
     log(f"embeddings: {int((~seen).sum())} of {len(vocab)} rows are float64 uniform draws (tokens the corpus never produces)")
-    eng.set_embeddings(emb)
+    parallel.sync_embeddings(eng, emb)
     upload_s = time.time() - t_up
     log(f"uploaded in {upload_s:.1f} s")
     bounds = segment_line_bounds(len(offsets) - 1, args.workers)
-    V = len(vocab)
-    H = HipSage.HIST_LEN
-    # the per-step N>1 path is the product's: sage_amd.dist.step_into = sage_ablation_step_device into torch CUDA
-    # tensors, then the combine over the process group (RCCL; staged through the host in the one-GPU rehearsal)
-    from sage_amd.dist import StepBuffers, step_into
-    buf = StepBuffers(V, H)
-    d_tot = buf.tot
+    V = model.id_space()
+    buf = StepBuffers(V, eng.hist_len)
 
-    def step():
+    def step():   # the product's per-step path: sage_ablation_step_device into torch CUDA tensors + combine
         step_into(eng, bounds, buf, dist if world > 1 else None)
 
     def fence():
@@ -198,39 +229,53 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         all_reduce_(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    total_tokens = int(d_tot[0].item())      # whole job (already combined over ranks)
-    total_triples = int(d_tot[1].item())
+    total_tokens = int(buf.tot[0].item())      # whole job (already combined over ranks)
+    total_triples = int(buf.tot[1].item())
     ms_per_step = dt / args.steps * 1e3
+    st = eng.step_stats()                      # this rank's shard (taken before the API timing below runs more steps)
+    kt = eng.kernel_times()
+
+    api_ms, api_parts = None, None
+    if world == 1 and not args.no_api_timing:
+        # SURVEY.md 8d's call: run_sage_parallel right after the prune loop's set_vocabulary (SaGeVocabBuilder.py:192),
+        # i.e. vocabulary table rebuild + upload, the step, and the result dicts.  Corpus and embeddings stay resident.
+        reps = []
+        for _ in range(3):
+            model.set_vocabulary(vocab)           # bumps vocab_version: the next call re-uploads the table
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            parallel.sync_vocab(eng, model)
+            tb = time.perf_counter()
+            tt_api, ttr_api, losses_api, sizes_api = parallel.run_sage_parallel(emb, packed, model, args.workers)
+            tc = time.perf_counter()
+            reps.append(((tc - ta) * 1e3, (tb - ta) * 1e3))
+        assert (tt_api, ttr_api) == (total_tokens, total_triples)
+        api_ms, vocab_ms = sorted(reps)[1]
+        api_parts = {"vocabulary_upload_ms": vocab_ms, "step_and_dicts_ms": api_ms - vocab_ms}
+        log(f"run_sage_parallel after set_vocabulary: {reps} ms (total, of which vocabulary upload)")
 
     if rank == 0:
-        st = eng.step_stats()                 # this rank's shard
-        kt = eng.kernel_times()
         # ---- algorithmic bytes, statistics measured on this very corpus ----
         tokens_local = st["tokens"]
+        occ = max(1, st["occurrences"])
         b_bar = st["corpus_bytes"] / tokens_local
         f_m = st["occurrences"] / tokens_local
-        r_bar = st["rows"] / max(1, st["occurrences"])
-        p_bar = st["records"] / max(1, st["occurrences"])
+        r_bar = st["rows"] / occ
+        p_bar = st["records"] / occ
         eb = st["emb_elem_bytes"]   # 4 when the rows are gathered from the lossless float32 copy, else 8
-        A = b_bar + 9 + f_m * (r_bar * args.dim * eb + 16 * p_bar)
-        per_kernel_bytes = {   # per step, this rank; DESIGN.md "Kernels" states each figure
-            "match": st["corpus_bytes"] * (1 + 1 + 8),
-            "walk": st["corpus_bytes"] * 8 / max(1.0, b_bar) * 2 + tokens_local * 8,
-            "count": st["pairs"] * 8 * 2,          # dedupe: every key record read and written once more (fine partition)
-            "partition": st["pairs"] * 8 + st["occurrences"] * 64,   # key scatter: descriptors in, one 8-byte record per pair out
-            "score": st["rows"] * args.dim * eb,
-            "describe": st["corpus_bytes"] * 8 + tokens_local * (8 + 64),
-            "pairs": tokens_local * (args.dim * eb + 16),
-            "logsig": st["pairs"] * 8 + st["occurrences"] * 64,
-            # float64 recomputation of the occurrences that touch a row the float32 copy cannot hold
-            "fix": st["f64_fix_occurrences"] * (r_bar * args.dim * 8 + 64),
-        }
+
+        def A_of(e):
+            return b_bar + 9 + f_m * (r_bar * args.dim * e + 16 * p_bar)
+        per_kernel_bytes = algorithmic_bytes(st, args.dim)
         dom = max(per_kernel_bytes, key=lambda k: kt[k][0])
         dom_ms, dom_n = kt[dom]
         launches_per_step = max(1, dom_n // args.steps)
         avg_ms = dom_ms / max(1, dom_n)
         achieved = per_kernel_bytes[dom] / launches_per_step / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        step_gbs = A * total_tokens / (dt / args.steps) / 1e9 / world
+        step_s = dt / args.steps
+
+        def step_gbs(e):
+            return A_of(e) * total_tokens / step_s / 1e9 / world
         out = {
             "metric": "corpus tokens scored/sec per ablation step (node) @262k vocab + HBM GB/s",
             "value": total_tokens * args.steps / dt,
@@ -239,6 +284,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            "run_sage_parallel_ms": api_ms,
+            "run_sage_parallel_parts": api_parts,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -248,23 +295,32 @@ def main():
                        "workload": f"{args.lines}-line synthetic {args.style}-wiki-shaped corpus per GPU, single "
                                    f"{args.vocab}-key vocabulary ablation step (tokenize + score + counts), D={args.dim}, "
                                    f"max_len={args.max_len}, pad=2, workers_number={args.workers}",
+                       "workload_shape": "substring-frequency vocabulary: ablations rejoin the base tokenization late, so this "
+                                         "corpus is harder than the survey's measured text (b 5.3 / f_m 0.93 / r 7.3 / p 24.4); "
+                                         "its own statistics are in step_roofline",
                        "lines_per_gpu": args.lines, "vocab": len(vocab), "dim": args.dim, "max_len": args.max_len,
                        "corpus_bytes_per_gpu": int(st["corpus_bytes"]), "total_tokens": total_tokens,
                        "total_triples": total_triples},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": CLASS_BOUND.get(dom, "hbm"),
+                         "kernel": dom, "kernel_name": CLASS_KERNEL.get(dom, dom),
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, args),
                          "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step,
                          "algorithmic_bytes_per_launch": per_kernel_bytes[dom] / launches_per_step,
-                         "note": ("k_match_lds is bound by VALU issue (15 prefix hashes + filter and table probes per corpus "
-                                  "byte; vector pipes ~92 % busy, profiles/r01_v12_sq_cycles.txt), not by HBM: see DESIGN.md, "
-                                  "Kernels") if dom == "match" else ""},
+                         "elem_bytes": eb,
+                         "note": "peak is HBM's 8 TB/s for every kernel; kernels whose bound is not 'hbm' are limited elsewhere "
+                                 "(score/pairs gather rows that live in L2 / Infinity Cache, match is VALU-issue bound): DESIGN.md, Kernels"},
             "step_roofline": {"measured_hbm_bytes_per_step": pmc_traffic("__step_total__", args) if world == 1 else None,
-                              "bytes_per_token_A": A, "achieved_GBs_per_gpu": step_gbs, "frac": step_gbs / HBM_PEAK_GBS,
+                              "bytes_per_token_A": A_of(eb), "achieved_GBs_per_gpu": step_gbs(eb), "frac": step_gbs(eb) / HBM_PEAK_GBS,
+                              "bytes_per_token_A_e8": A_of(8), "frac_e8": step_gbs(8) / HBM_PEAK_GBS,
                               "b_bar": b_bar, "f_m": f_m, "r_bar": r_bar, "p_bar": p_bar, "emb_elem_bytes": eb,
+                              "window_rows_per_occurrence": st["window_rows"] / occ,
+                              "window_pairs_per_occurrence": st["window_pairs"] / occ,
+                              "long_occurrence_share": st["long_occurrences"] / occ,
                               "f64_fix_occurrences": st["f64_fix_occurrences"]},
             "kernel_ms_per_step": {k: kt[k][0] / args.steps for k in kt},
             # every kernel class against the HBM roofline: algorithmic bytes per step / its time per step
-            "kernel_roofline": {k: {"algorithmic_GB_per_step": per_kernel_bytes[k] / 1e9,
+            "kernel_roofline": {k: {"algorithmic_GB_per_step": per_kernel_bytes[k] / 1e9, "bound": CLASS_BOUND.get(k),
                                     "GBps": per_kernel_bytes[k] / (kt[k][0] / args.steps * 1e-3) / 1e9 if kt[k][0] > 0 else 0.0,
                                     "frac": per_kernel_bytes[k] / (kt[k][0] / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS if kt[k][0] > 0 else 0.0}
                                 for k in per_kernel_bytes},

@@ -172,10 +172,14 @@ int sage_train_embeddings(sage_ctx* ctx, int32_t dim, int32_t window, int32_t ne
                           double* out_vectors /*[vsize*dim]*/, int64_t* out_counts /*[vsize]*/);
 
 /* Workload statistics of the last step, for the roofline's algorithmic bytes:
- * out[0]=tokens, out[1]=corpus bytes, out[2]=ablated occurrences, out[3]=embedding rows touched,
- * out[4]=signed pair records, out[5]=distinct-count probes inserted, out[6]=bytes per stored embedding element on
- * the main scoring pass (4 or 8), out[7]=occurrences recomputed from the float64 matrix. */
-int sage_get_step_stats(sage_ctx* ctx, int64_t* out /*[8]*/);
+ * out[0]=tokens, out[1]=corpus bytes, out[2]=ablated occurrences, out[3]=embedding rows touched (ablated windows +
+ * base spans), out[4]=signed pair records, out[5]=unordered position pairs (= records / 2: what the distinct count
+ * partitions), out[6]=bytes per stored embedding element on the main scoring pass (4 or 8), out[7]=occurrences
+ * recomputed from the float64 matrix, out[8]=ids of the ablated windows (the rows the window-dot kernel gathers),
+ * out[9]=occurrences whose window is kept in the id pool, out[10]=embedding dimension, out[11]=padded row width in
+ * elements, out[12]=position pairs of the ablated windows (dot products evaluated), out[13..15]=0 (reserved). */
+#define SAGE_STEP_STATS 16
+int sage_get_step_stats(sage_ctx* ctx, int64_t* out /*[SAGE_STEP_STATS]*/);
 
 #ifdef __cplusplus
 }

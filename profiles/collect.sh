@@ -6,8 +6,8 @@ set -o pipefail
 export TMPDIR=/tmp
 O=gpurun_out/prof
 rm -rf $O && mkdir -p $O
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt -o run --output-format csv -- python3 bench.py --steps 3 --warmup 1 --cpu-lines -1 > $O/bench_kt.json 2> $O/bench_kt.err || exit 1
-timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o run --output-format csv -- python3 bench.py --steps 1 --warmup 0 --cpu-lines -1 > $O/bench_fetch.json 2> $O/bench_fetch.err || exit 1
-timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE -d $O/write -o run --output-format csv -- python3 bench.py --steps 1 --warmup 0 --cpu-lines -1 > $O/bench_write.json 2> $O/bench_write.err || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/kt -o run --output-format csv -- python3 bench.py --steps 3 --warmup 1 --cpu-lines -1 --no-api-timing > $O/bench_kt.json 2> $O/bench_kt.err || exit 1
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o run --output-format csv -- python3 bench.py --steps 1 --warmup 0 --cpu-lines -1 --no-api-timing > $O/bench_fetch.json 2> $O/bench_fetch.err || exit 1
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE -d $O/write -o run --output-format csv -- python3 bench.py --steps 1 --warmup 0 --cpu-lines -1 --no-api-timing > $O/bench_write.json 2> $O/bench_write.err || exit 1
 timeout -k 10 600 python3 -u bench.py > $O/bench_full.json 2> $O/bench_full.err || exit 1
 tail -c 400 $O/bench_full.json

@@ -139,6 +139,15 @@ class HipSage:
                                              _ptr(ids_arr, C.c_int32), len(keys), int(max_len)))
         self.vsize = (int(ids_arr.max()) if ids_arr is not None else len(keys) - 1) + 1
 
+    def set_vocab_packed(self, flat: np.ndarray, off: np.ndarray, ids, max_len: int = 16):
+        """The same from arrays that are already packed (SaGeTokenizer.packed_key_table)."""
+        n = len(off) - 1
+        buf = flat if flat.size else np.zeros(1, dtype=np.uint8)
+        ids_arr = None if ids is None else np.ascontiguousarray(ids, dtype=np.int32)
+        self._check(self._lib.sage_set_vocab(self._h, _ptr(buf, C.c_uint8), _ptr(off, C.c_int64),
+                                             _ptr(ids_arr, C.c_int32), n, int(max_len)))
+        self.vsize = (int(ids_arr.max()) if ids_arr is not None else n - 1) + 1
+
     def set_corpus(self, corpus: np.ndarray, line_offsets: np.ndarray):
         corpus = np.ascontiguousarray(corpus, dtype=np.uint8)
         line_offsets = np.ascontiguousarray(line_offsets, dtype=np.int64)
@@ -248,8 +257,9 @@ class HipSage:
         return vec, counts
 
     def step_stats(self):
-        out = np.zeros(8, dtype=np.int64)
+        out = np.zeros(16, dtype=np.int64)
         self._check(self._lib.sage_get_step_stats(self._h, _ptr(out, C.c_int64)))
         return {"tokens": int(out[0]), "corpus_bytes": int(out[1]), "occurrences": int(out[2]),
                 "rows": int(out[3]), "records": int(out[4]), "pairs": int(out[5]), "emb_elem_bytes": int(out[6]),
-                "f64_fix_occurrences": int(out[7])}
+                "f64_fix_occurrences": int(out[7]), "window_rows": int(out[8]), "long_occurrences": int(out[9]),
+                "dim": int(out[10]), "padded_dim": int(out[11]), "window_pairs": int(out[12])}

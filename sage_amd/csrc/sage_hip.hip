@@ -106,7 +106,7 @@ struct sage_ctx {
     std::vector<hipEvent_t> ev_free;
     double k_ms[SAGE_K_NCLASSES] = {0};
     int64_t k_launches[SAGE_K_NCLASSES] = {0};
-    int64_t step_stats[8] = {0};
+    int64_t step_stats[SAGE_STEP_STATS] = {0};
 };
 
 namespace {
@@ -649,6 +649,11 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
         c->step_stats[5] = (int64_t)stats[STAT_PAIRS];
         c->step_stats[6] = c->use_f32 ? 4 : 8;   // bytes per stored embedding element on the main scoring pass
         c->step_stats[7] = (int64_t)stats[STAT_INEXACT];
+        c->step_stats[8] = (int64_t)stats[STAT_WROWS];
+        c->step_stats[9] = (int64_t)stats[STAT_LONG];
+        c->step_stats[10] = (int64_t)c->dim;
+        c->step_stats[11] = (int64_t)c->dp;
+        c->step_stats[12] = (int64_t)stats[STAT_ABPAIRS];
         // The share of ROWS that float32 cannot hold says little about the share of OCCURRENCES that touch one; the
         // step just measured the latter.  Above 30 % the float64 pass costs more than the float32 copy saves: later
         // steps (until the next sage_set_embeddings) use the float64 matrix alone.  Results do not depend on this.
@@ -1217,7 +1222,7 @@ int sage_set_count_mode(sage_ctx* c, int mode) {
 
 int sage_get_step_stats(sage_ctx* c, int64_t* out) {
     if (!c || !out) return SAGE_E_ARG;
-    for (int i = 0; i < 8; ++i) out[i] = c->step_stats[i];
+    for (int i = 0; i < SAGE_STEP_STATS; ++i) out[i] = c->step_stats[i];
     return SAGE_OK;
 }
 

@@ -22,7 +22,9 @@ struct VocabDev {
 };
 
 enum { FLAG_SET_OVERFLOW = 0, FLAG_ROW_OOB = 1, FLAG_EMPTY_LINE = 2, FLAG_COUNT = 8 };
-enum { STAT_OCC = 0, STAT_ROWS = 1, STAT_PAIRS = 2, STAT_DISTINCT = 3, STAT_INEXACT = 4, STAT_COUNT = 8 };
+enum { STAT_OCC = 0, STAT_ROWS = 1, STAT_PAIRS = 2, STAT_DISTINCT = 3, STAT_INEXACT = 4, STAT_WROWS = 5 /* ids of the ablated windows: the rows k_dots gathers */,
+       STAT_LONG = 6 /* occurrences whose window went to the id pool */, STAT_ABPAIRS = 7 /* position pairs of the ablated windows */,
+       STAT_COUNT = 8 };
 
 // ----------------------------------------------------------------------------------------------------------
 // rem[p] = min(255, line_end(p) - p): one byte per corpus byte, computed once per corpus (set_corpus).

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
     if (threadIdx.x < SEG_LDS) lseg[threadIdx.x] = 0ull;
     for (uint32_t i = threadIdx.x; i < DESC_ACC; i += 256) { occ_id[i] = ACC_EMPTY; occ_n[i] = 0; }
     __syncthreads();
-    unsigned long long n_rows = 0, n_pairs = 0;
+    unsigned long long n_rows = 0, n_pairs = 0, n_wrows = 0, n_ab = 0;
     const uint32_t n_items = LONG ? *long_count : n_occ;
     const uint32_t n_round = (n_items + 255u) & ~255u;
     uint32_t* my = rows + (LONG ? 0 : threadIdx.x * DESC_LDS_STRIDE);
@@ -243,6 +243,8 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
                 const uint32_t ab_pairs = window_pairs(w.pl, w.k, w.pr);
                 my_pairs = (unsigned long long)ab_pairs + window_pairs(w.pl, w.m, w.pr);
                 n_rows += L + w.m;
+                n_wrows += L;
+                n_ab += ab_pairs;
                 npairs_ab[o] = ab_pairs;
                 acc_add_u32<DESC_ACC_BITS>(occ_id, occ_n, occ, w.a);
                 const uint32_t kk = w.k < hist_len ? w.k : hist_len - 1u;
@@ -295,11 +297,16 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
     for (int d = 32; d >= 1; d >>= 1) {
         n_rows += __shfl_down(n_rows, d, 64);
         n_pairs += __shfl_down(n_pairs, d, 64);
+        n_wrows += __shfl_down(n_wrows, d, 64);
+        n_ab += __shfl_down(n_ab, d, 64);
     }
     if (lane == 0) {
         if (n_rows) atomicAdd(&stats[STAT_ROWS], n_rows);
         if (n_pairs) atomicAdd(&stats[STAT_PAIRS], n_pairs);
+        if (n_wrows) atomicAdd(&stats[STAT_WROWS], n_wrows);
+        if (n_ab) atomicAdd(&stats[STAT_ABPAIRS], n_ab);
     }
+    if (LONG && blockIdx.x == 0 && threadIdx.x == 0 && n_items) atomicAdd(&stats[STAT_LONG], (unsigned long long)n_items);
 }
 
 // Row slice of one lane: EPL doubles as EPL/2 16-byte loads; the G lanes of a group cover one 128-byte line per

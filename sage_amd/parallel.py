@@ -131,8 +131,8 @@ def sync_vocab(engine: HipSage, sage_model) -> None:
     tag = (sage_model.vocab_version, sage_model.max_len)
     hit = engine.cache.get("vocab")
     if hit is None or hit[0] is not sage_model or hit[1] != tag:
-        keys, ids = sage_model.key_table()
-        engine.set_vocab(keys, ids, sage_model.max_len)
+        flat, off, ids = sage_model.packed_key_table()
+        engine.set_vocab_packed(flat, off, ids, sage_model.max_len)
         engine.cache["vocab"] = (sage_model, tag)
 
 

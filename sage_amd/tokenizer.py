@@ -28,8 +28,10 @@ class SaGeTokenizer:
         self.hfe = HFEncoding()
         self.byte_vocab: Dict[bytes, int] = None
         self.inv_byte_vocab: Dict[int, bytes] = None
-        self.str_vocab: Dict[str, int] = None
-        self.inv_str_vocab: Dict[int, str] = None
+        self._str_vocab = None              # the two string-keyed dicts are built when first read (files, gensim)
+        self._inv_str_vocab = None
+        self._encoded: Dict[bytes, str] = {}    # HF-encoded form of every key seen so far (keys survive prunes)
+        self._packed = None                 # (key bytes uint8, key offsets int64, ids int32): what the engine uploads
         self.vocab_version = 0      # bumped on every set_vocabulary; engines re-upload when it changes
         self.max_len = max_len
         self.set_vocabulary(initial_vocabulary)
@@ -48,11 +50,39 @@ class SaGeTokenizer:
         require_all_single_bytes(table)
         self.byte_vocab = table
         self.inv_byte_vocab = {i: k for k, i in table.items()}
-        enc = self.hfe.to_encoded
-        self.str_vocab = {enc(k): i for k, i in table.items()}
-        self.inv_str_vocab = {i: s for s, i in self.str_vocab.items()}
+        self._str_vocab = self._inv_str_vocab = None
         self._id_space = len(new_vocab)     # ids are list positions (model.py:44-51)
+        # The device table is packed here, where the reference rebuilds its own lookup tables, so that the ablation
+        # step that follows a prune (SaGeVocabBuilder.py:192 -> :100) only has to hash and upload it.
+        keys = new_vocab if len(table) == len(new_vocab) else list(table.keys())
+        ids = None if keys is new_vocab else np.fromiter(table.values(), dtype=np.int32, count=len(table))
+        off = np.zeros(len(keys) + 1, dtype=np.int64)
+        np.cumsum(np.fromiter(map(len, keys), dtype=np.int64, count=len(keys)), out=off[1:])
+        self._packed = (np.frombuffer(b"".join(keys), dtype=np.uint8), off, ids)
         self.vocab_version += 1
+
+    def _build_str_vocabs(self) -> None:
+        enc, cache = self.hfe.to_encoded, self._encoded
+        out = {}
+        for k, i in self.byte_vocab.items():
+            s = cache.get(k)
+            if s is None:
+                s = cache[k] = enc(k)
+            out[s] = i
+        self._str_vocab = out
+        self._inv_str_vocab = {i: s for s, i in out.items()}
+
+    @property
+    def str_vocab(self) -> Dict[str, int]:
+        if self._str_vocab is None:
+            self._build_str_vocabs()
+        return self._str_vocab
+
+    @property
+    def inv_str_vocab(self) -> Dict[int, str]:
+        if self._inv_str_vocab is None:
+            self._build_str_vocabs()
+        return self._inv_str_vocab
 
     def id_to_bytes(self, token_id: int) -> bytes:
         return self.inv_byte_vocab[token_id]
@@ -102,3 +132,7 @@ class SaGeTokenizer:
         keys = list(self.byte_vocab.keys())
         ids = np.fromiter(self.byte_vocab.values(), dtype=np.int32, count=len(keys))
         return keys, ids
+
+    def packed_key_table(self):
+        """(key bytes uint8, key offsets int64[n+1], ids int32[n] or None = positions), packed by set_vocabulary."""
+        return self._packed

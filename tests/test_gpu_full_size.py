@@ -1,42 +1,63 @@
-"""GPU: the BASELINE.json workload itself (1,000,000 lines, 262,144 keys, D=50, max_len=16, workers_number=4 -- what
-bench.py times), checked through properties that need no oracle at this size: the step over all count segments is the
-sum of the steps over two halves (integers exact, losses to 1e-9), an independent distinct-count back end (per-segment
-HBM sets, count mode 1) and the unfiltered matcher give the same integers, and the totals tie together.  The value of
-total_triples is also pinned to what every build of this repository since v1 has produced on this corpus
-(profiles/r01_v*_bench_full.json): a regression pin, NOT an oracle value -- the oracle pins the algorithm at small
-sizes (tests/test_gpu_parity.py), this pins the large-size plumbing (batches, 32-bit offsets, bucket sizing)."""
+"""GPU: the BASELINE.json workloads at full single-GPU size, checked through properties that need no oracle at this
+size.  configs[1]: 1,000,000 English lines, 262,144 keys, D=50, max_len=16, workers_number=4 (what bench.py times);
+configs[3]'s shape: Turkish-style multi-byte corpus, max_len 17, 1,000,000 lines (0.95 GB; the 5M-line run is a bench
+line); configs[4]'s shape: D=300 on the English corpus.  Properties: the step over all count segments is
+the sum of the steps over two halves (integers exact, losses to 1e-9), an independent distinct-count back end
+(per-segment HBM sets, count mode 1) and the unfiltered matcher give the same integers, float64 row storage gives the
+same losses as the float32 copy, and the totals tie together.  On the English corpus total_tokens / total_triples are
+also pinned to what every build of this repository since v1 has produced (profiles/r01_v*_bench_full.json): a
+regression pin, NOT an oracle value -- the oracle pins the algorithm at small sizes (tests/test_gpu_parity.py), this
+pins the large-size plumbing (batches, 32-bit offsets, bucket sizing).  D does not enter the integers, so the D=300
+run must reproduce the same pins."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 N_LINES = 1_000_000
-PINNED_TOTAL_TOKENS = 86_193_104
-PINNED_TOTAL_TRIPLES = 3_311_102_221
+PINNED = {"en": (86_193_104, 3_311_102_221)}
+_inputs = {}
 
 
-def test_baseline_workload_properties():
+def _corpus_and_vocab(style, max_len):
+    from sage_amd import synth
+    key = (style, max_len)
+    if key not in _inputs:
+        _inputs.clear()                       # one corpus at a time in host memory
+        seed = synth.DEFAULT_SEED
+        head, head_off = synth.make_corpus(14_000, seed=seed, style=style, n_types=1_000_000)
+        vocab = synth.make_vocab(head, head_off, 262_144, max_len, sample_bytes=6_000_000)
+        corpus, off = synth.make_corpus(N_LINES, seed=seed, style=style, n_types=1_000_000)
+        _inputs[key] = (vocab, corpus, off)
+    return _inputs[key]
+
+
+@pytest.mark.parametrize("style,max_len,dim", [("en", 16, 50), ("en", 16, 300), ("tr", 17, 50)])
+def test_full_size_workload_properties(style, max_len, dim):
     from sage_amd import synth
     from sage_amd._lib import HipSage
     from sage_amd.parallel import segment_line_bounds
-    seed = synth.DEFAULT_SEED
-    head, head_off = synth.make_corpus(14_000, seed=seed, style="en", n_types=1_000_000)
-    vocab = synth.make_vocab(head, head_off, 262_144, 16, sample_bytes=6_000_000)
-    corpus, off = synth.make_corpus(N_LINES, seed=seed, style="en", n_types=1_000_000)
+    vocab, corpus, off = _corpus_and_vocab(style, max_len)
     eng = HipSage(0)
     try:
-        eng.set_vocab(vocab, None, 16)
+        eng.set_vocab(vocab, None, max_len)
         eng.set_corpus(corpus, off)
         per_line, total = eng.token_counts(0, N_LINES)
         counts = np.bincount(eng.tokenize(0, N_LINES)[0], minlength=len(vocab))
-        emb = synth.make_embeddings(len(vocab), 50, seed=seed, unseen=~(counts > 0))
+        emb = synth.make_embeddings(len(vocab), dim, seed=synth.DEFAULT_SEED, unseen=~(counts > 0))
         eng.set_embeddings(emb)
         bounds = segment_line_bounds(N_LINES, 4)
         loss, occ, tt, ttr, hist = eng.ablation_step(bounds)
-        assert tt == total == int(counts.sum()) == int(per_line.sum()) == PINNED_TOTAL_TOKENS
-        assert ttr == PINNED_TOTAL_TRIPLES
+        assert tt == total == int(counts.sum()) == int(per_line.sum())
+        if style in PINNED:
+            assert (tt, ttr) == PINNED[style]
         assert int(hist.sum()) == int(occ.sum()) and np.isfinite(loss).all()
         assert not np.any((occ > 0) & (counts == 0))          # only tokens the tokenization produces are ablated
+        multi = np.array([len(v) > 1 for v in vocab])
+        assert np.array_equal(occ[multi], counts[multi]) and not occ[~multi].any()   # every multi-byte token is ablated once
+        st = eng.step_stats()
+        assert st["tokens"] == tt and st["occurrences"] == int(occ.sum()) and st["emb_elem_bytes"] == 4
+        assert st["records"] == 2 * st["pairs"] and 0 < st["window_rows"] < st["rows"]
         # halves add up (what sharding over GPUs relies on)
         n_seg = len(bounds) - 1
         mid = n_seg // 2
@@ -54,5 +75,11 @@ def test_baseline_workload_properties():
         _, o4, t4, r4, h4 = eng.ablation_step(bounds[mid:])
         eng.set_match_mode(0)
         assert (t4, r4) == (t2, r2) and np.array_equal(o4, o2) and np.array_equal(h4, h2)
+        # float64 row storage (no float32 copy, no fix-up pass) scores the same
+        eng.set_score_mode(1)
+        eng.set_embeddings(emb)
+        l5, o5, t5, r5, h5 = eng.ablation_step(bounds[:mid + 1])
+        assert (t5, r5) == (t1, r1) and np.array_equal(o5, o1)
+        np.testing.assert_allclose(l5, l1, rtol=1e-9, atol=1e-12 * np.abs(loss).max())
     finally:
         eng.close()

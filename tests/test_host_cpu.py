@@ -73,12 +73,7 @@ def test_vocab_and_loss_file_formats(tmp_path):
     with pytest.raises(FileNotFoundError):
         hostio.load_vocab(tmp_path / "absent.vocab")
     # rebuild the first round's files from its golden sorted-loss file
-    model = SaGeTokenizer.__new__(SaGeTokenizer)      # host state only; no GPU
-    from sage_amd.hf_bytes import HFEncoding
-    model.hfe = HFEncoding()
-    model.vocab_version = 0
-    model.max_len = 16
-    model.set_vocabulary(vocab)
+    model = SaGeTokenizer(vocab, 16)                  # host state only; no GPU is touched until something is tokenized
     want = files["sage_vocabs/sorted_losses_before_2300.txt"]
     ranked = []
     for ln in want.splitlines():
@@ -107,6 +102,12 @@ def test_tokenizer_vocab_state_matches_reference_rules():
     assert t.vocab_size() == 258 and t.get_vocabulary()[b"ab"] == 258 and t.id_to_bytes(257) == b"abc"
     keys, ids = t.key_table()
     assert dict(zip(keys, ids.tolist())) == t.get_vocabulary()
+    flat, off, pids = t.packed_key_table()            # what the engine uploads: the same table, packed
+    assert {flat[off[i]:off[i + 1]].tobytes(): int(pids[i]) for i in range(len(off) - 1)} == t.get_vocabulary()
+    t2 = SaGeTokenizer(vocab[:-1], 16)                # no repeats: ids are the positions
+    flat, off, pids = t2.packed_key_table()
+    assert pids is None and [flat[off[i]:off[i + 1]].tobytes() for i in range(len(off) - 1)] == vocab[:-1]
+    assert t2.id_space() == 258 and t.id_space() == 259 and t.str_vocab["ab"] == 258 and t.inv_str_vocab[257] == "abc"
     d = {}
     t.add_all_byte_ids(d, 1e6)
     assert len(d) == 256 and set(d.values()) == {1e6}
