@@ -81,11 +81,17 @@ SAGE_HD uint32_t sage_key_hash_b(uint64_t k) {
 
 // Occurrence descriptor: 16 u32 per base token.  word 0 = header, words 1.. = the ablated window
 // [left pads | x1..xk | right pads] (at most SAGE_DESC_MAXWIN ids, otherwise OVER is set and the slow path runs).
+// Distinct count (sage_kernels3.h): a workgroup stages the keys of a tile of occurrences in LDS; an occurrence with more
+// position pairs than this is not part of any tile.  Inline descriptors keep their base span at or below
+// SAGE_INLINE_MAX_M tokens so that an inline occurrence can never be a giant.
+#define SAGE_PART_GIANT 2048u
+#define SAGE_INLINE_MAX_M 255u
 #define SAGE_DESC_WORDS 16
 #define SAGE_DESC_MAXWIN 15
 #define SAGE_DH_VALID 0x80000000u
 #define SAGE_DH_OVER 0x40000000u
 #define SAGE_DH_NEVER 0x20000000u
+#define SAGE_DH_GIANT 0x10000000u   // more than SAGE_PART_GIANT position pairs: the distinct count's slow path
 #define SAGE_DH_K(h) ((h) & 0xFFFu)
 #define SAGE_DH_M(h) (((h) >> 12) & 0xFFFu)
 #define SAGE_DH_PL(h) (((h) >> 24) & 3u)

@@ -89,8 +89,9 @@ struct sage_ctx {
     int score_mode = 0;   // 0 = float32 storage when lossless for most rows, 1 = always float64 storage
 
     // scratch (grow-only; nothing is allocated in the steady state)
-    DevBuf M, ntok, tokoff, tile_sums, grand_total, tok_w0, occ_pos, set, seg_line_rel, seg_tok_off, set_base, set_mask, seg_pairs, desc, gcache, hist1, bucket_off, bucket_lim, rec_a, rec_b,
-        nocc, occoff, occ_tok, np_ab, dot_off, dots, pool, pool_cursor;
+    DevBuf M, ntok, tokoff, tile_sums, grand_total, tok_w0, occ_pos, set, seg_line_rel, seg_tok_off, set_base, set_mask, seg_pairs, desc, gcache, bucket_off, rec_a,
+        nocc, occoff, occ_tok, np_ab, dot_off, dots, pool, pool_cursor,
+        np_all, pair_off, seg_first_occ, seg_tile_off, seg_bucket_base, seg_nbk_mask, cursor, giant_list, giant_count, tile_tab;
     int pool_factor = 8;  // id-pool words per occurrence (grown on overflow)
     bool exact_buckets = false;   // v2 count: size the key buckets with a counting pass instead of the estimate
     int count_mode = 0;  // 0 = partition + LDS dedupe (v2), 1 = per-segment HBM sets (v1)
@@ -483,15 +484,20 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
             }
             SegPlan S{c->seg_tok_off.as<uint32_t>(), c->set_base.as<uint64_t>(), c->set_mask.as<uint64_t>(), nsb};
             const uint32_t cgrid = std::min<uint32_t>(cdiv(n_occ, 256), 256u * 16u);
-            const uint32_t pgrid = std::min<uint32_t>(cdiv(n_occ, PART_TILE), 256u * 16u);
             const uint32_t lgrid = std::min<uint32_t>(cdiv(n_occ, 256), 256u * 8u);   // long-list kernels (grid-stride)
             if ((rc = ensure(c, c->long_list, (size_t)n_occ * 4))) return rc;
             if ((rc = ensure(c, c->long_count, 4))) return rc;
+            if ((rc = ensure(c, c->giant_list, (size_t)n_occ * 4))) return rc;
+            if ((rc = ensure(c, c->giant_count, 4))) return rc;
+            if ((rc = ensure(c, c->np_all, (size_t)n_occ * 4))) return rc;
+            if ((rc = ensure(c, c->pair_off, ((size_t)n_occ + 1) * 4))) return rc;
             HIP_TRY(c, hipMemsetAsync(c->long_count.p, 0, 4, c->stream));
+            HIP_TRY(c, hipMemsetAsync(c->giant_count.p, 0, 4, c->stream));
             {
                 Prof p(c, SAGE_K_DESCRIBE);
                 k_describe<false><<<cgrid, 256, 0, c->stream>>>(
                     A, c->occ_tok.as<uint32_t>(), n_occ, S, c->desc.as<uint4>(), c->np_ab.as<uint32_t>(),
+                    c->np_all.as<uint32_t>(), c->giant_list.as<uint32_t>(), c->giant_count.as<uint32_t>(),
                     c->pool.as<uint32_t>(), c->pool_cursor.as<uint32_t>(), (uint32_t)pool_cap,
                     c->seg_pairs.as<unsigned long long>(), c->occ.as<unsigned long long>(),
                     c->hist.as<unsigned long long>(), (uint32_t)hist_len, c->stats.as<unsigned long long>(),
@@ -501,6 +507,7 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
                 Prof p(c, SAGE_K_MISC);   // the long-occurrence kernels are accounted under "misc"
                 k_describe<true><<<lgrid, 256, 0, c->stream>>>(
                     A, c->occ_tok.as<uint32_t>(), n_occ, S, c->desc.as<uint4>(), c->np_ab.as<uint32_t>(),
+                    c->np_all.as<uint32_t>(), c->giant_list.as<uint32_t>(), c->giant_count.as<uint32_t>(),
                     c->pool.as<uint32_t>(), c->pool_cursor.as<uint32_t>(), (uint32_t)pool_cap,
                     c->seg_pairs.as<unsigned long long>(), c->occ.as<unsigned long long>(),
                     c->hist.as<unsigned long long>(), (uint32_t)hist_len, c->stats.as<unsigned long long>(),
@@ -511,79 +518,113 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
 
             uint64_t n_dots = 0;
             if (c->count_mode == 0 && !c->count_fallback) {
-                // ---- v2: hash-partition the key stream, dedupe each bucket in LDS ----
-                const size_t nbk = (size_t)nsb * NB1;
-                if ((rc = ensure(c, c->hist1, nbk * 8))) return rc;
-                if ((rc = ensure(c, c->bucket_off, (nbk + 1) * 8))) return rc;
-                if ((rc = ensure(c, c->bucket_lim, nbk * 8))) return rc;
-                std::vector<uint64_t> boff(nbk + 1), blim(nbk);
+                // ---- default: one partition level into LDS-set-sized buckets, every record read once (sage_kernels3.h) ----
+                if ((rc = scan_u32(c, c->np_all.as<uint32_t>(), n_occ, c->pair_off.as<uint32_t>(), c->grand_total.as<uint64_t>()))) return rc;
+                if ((rc = ensure(c, c->seg_first_occ, (size_t)(nsb + 1) * 4))) return rc;
+                if ((rc = ensure(c, c->seg_tile_off, (size_t)(nsb + 1) * 4))) return rc;
+                if ((rc = ensure(c, c->seg_bucket_base, (size_t)(nsb + 1) * 4))) return rc;
+                if ((rc = ensure(c, c->seg_nbk_mask, (size_t)nsb * 4))) return rc;
+                k_tile_plan<<<1, 256, 0, c->stream>>>(c->occ_tok.as<uint32_t>(), n_occ, c->seg_tok_off.as<uint32_t>(), nsb,
+                                                      c->pair_off.as<uint32_t>(), c->seg_first_occ.as<uint32_t>(),
+                                                      c->seg_tile_off.as<uint32_t>());
+                std::vector<uint64_t> spairs(nsb);
+                uint64_t gt2[2] = {0, 0};
+                HIP_TRY(c, hipMemcpyAsync(spairs.data(), c->seg_pairs.p, (size_t)nsb * 8, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipMemcpyAsync(gt2, c->grand_total.p, 16, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                n_dots = gt2[1];
+                if (gt2[0] >= 0xFFFFFF00ull) return fail(c, SAGE_E_LIMIT, "a batch must stay under 2^32 position pairs");
+                // buckets per segment: a power of two that keeps a bucket near 8k records (one pass of the 16k-slot LDS set)
+                std::vector<uint32_t> bbase(nsb + 1), bmask(nsb);
+                uint32_t nbk_total = 0;
+                for (uint32_t s2 = 0; s2 < nsb; ++s2) {
+                    uint32_t nbk = 1;
+                    while (nbk < PART_NBK_MAX && (uint64_t)nbk * 8192u < spairs[s2]) nbk <<= 1;
+                    bbase[s2] = nbk_total; bmask[s2] = nbk - 1u; nbk_total += nbk;
+                }
+                bbase[nsb] = nbk_total;
+                uint64_t max_tiles64 = 0;       // tiles are cut per segment: an upper bound from the segments' pair totals
+                for (uint32_t s2 = 0; s2 < nsb; ++s2) max_tiles64 += (spairs[s2] + PART_FILL - 1) / PART_FILL;
+                const uint32_t max_tiles = (uint32_t)std::max<uint64_t>(max_tiles64, 1);
+                if ((rc = ensure(c, c->tile_tab, (size_t)max_tiles * 16))) return rc;
+                if ((rc = ensure(c, c->cursor, (size_t)std::max(nbk_total, 1u) * 4))) return rc;
+                if ((rc = ensure(c, c->bucket_off, ((size_t)nbk_total + 1) * 8))) return rc;
+                HIP_TRY(c, hipMemcpyAsync(c->seg_bucket_base.p, bbase.data(), (size_t)(nsb + 1) * 4, hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(c, hipMemcpyAsync(c->seg_nbk_mask.p, bmask.data(), (size_t)nsb * 4, hipMemcpyHostToDevice, c->stream));
+                PartPlan PP{c->pair_off.as<uint32_t>(), c->seg_first_occ.as<uint32_t>(), c->seg_tile_off.as<uint32_t>(),
+                            c->seg_bucket_base.as<uint32_t>(), c->seg_nbk_mask.as<uint32_t>(),
+                            c->bucket_off.as<unsigned long long>(), nsb};
+                static bool lds_set = false;
+                const size_t part_lds = (size_t)PART_STAGE * 8 + ((size_t)PART_NBK_MAX * 3 + PART_LONGS + 24) * 4;
+                const size_t set_lds = (size_t)SET3_SLOTS * 8;
+                if (!lds_set) {   // more than 64 KiB of dynamic LDS has to be asked for (once per process)
+                    HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_key_partition3<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds));
+                    HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_key_partition3<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds));
+                    HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_key_dedupe3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)set_lds));
+                    lds_set = true;
+                }
+                k_tile_table<<<std::min<uint32_t>(cdiv(max_tiles, 256), 1024u), 256, 0, c->stream>>>(PP, max_tiles, c->tile_tab.as<uint4>());
+                const uint32_t tgrid = (uint32_t)c->n_cu;      // persistent: the stage fills a CU's LDS
+                const uint32_t ggrid = 64u;
+                std::vector<uint64_t> boff((size_t)nbk_total + 1);
                 uint64_t total = 0;
                 if (c->exact_buckets) {
-                    // counting pass: exact bucket sizes
-                    HIP_TRY(c, hipMemsetAsync(c->hist1.p, 0, nbk * 8, c->stream));
+                    // counting pass: exact bucket sizes (taken after an estimated region overflowed)
+                    HIP_TRY(c, hipMemsetAsync(c->cursor.p, 0, (size_t)std::max(nbk_total, 1u) * 4, c->stream));
                     {
                         Prof p(c, SAGE_K_PARTITION);
-                        k_key_partition<0><<<pgrid, PART_TILE, 0, c->stream>>>(c->desc.as<uint4>(), c->pool.as<uint32_t>(),
-                                                                         c->occ_tok.as<uint32_t>(), A.tok_w0, n_occ, S,
-                                                                         c->hist1.as<unsigned long long>(), nullptr, nullptr,
-                                                                         c->flags.as<uint32_t>());
-                        k_key_partition_long<0><<<lgrid, 256, 0, c->stream>>>(
-                            c->desc.as<uint4>(), c->pool.as<uint32_t>(), c->occ_tok.as<uint32_t>(), A.tok_w0,
-                            c->long_list.as<uint32_t>(), c->long_count.as<uint32_t>(), S, c->hist1.as<unsigned long long>(),
-                            nullptr, nullptr, c->flags.as<uint32_t>());
+                        k_key_partition3<0><<<tgrid, PART_THREADS, part_lds, c->stream>>>(
+                            c->desc.as<uint4>(), c->pool.as<uint32_t>(), c->occ_tok.as<uint32_t>(), A.tok_w0, PP,
+                            c->tile_tab.as<uint4>(), max_tiles, c->cursor.as<uint32_t>(), nullptr, c->flags.as<uint32_t>());
+                        k_key_giant<0><<<ggrid, 256, 0, c->stream>>>(c->desc.as<uint4>(), c->pool.as<uint32_t>(),
+                                                                     c->occ_tok.as<uint32_t>(), A.tok_w0,
+                                                                     c->giant_list.as<uint32_t>(), c->giant_count.as<uint32_t>(), S, PP,
+                                                                     c->cursor.as<uint32_t>(), nullptr, c->flags.as<uint32_t>());
                     }
-                    std::vector<uint64_t> h1(nbk);
-                    HIP_TRY(c, hipMemcpyAsync(h1.data(), c->hist1.p, nbk * 8, hipMemcpyDeviceToHost, c->stream));
-                    HIP_TRY(c, hipMemcpyAsync(&n_dots, c->grand_total.as<uint64_t>() + 1, 8, hipMemcpyDeviceToHost, c->stream));
+                    std::vector<uint32_t> cnts(nbk_total);
+                    HIP_TRY(c, hipMemcpyAsync(cnts.data(), c->cursor.p, (size_t)nbk_total * 4, hipMemcpyDeviceToHost, c->stream));
                     HIP_TRY(c, hipStreamSynchronize(c->stream));
-                    for (size_t i = 0; i < nbk; ++i) { boff[i] = total; total += h1[i]; blim[i] = total; }
+                    for (uint32_t b2 = 0; b2 < nbk_total; ++b2) { boff[b2] = total; total += cnts[b2]; }
                 } else {
-                    // no counting pass: the hash spreads a segment's pairs evenly over its 64 buckets, so each region is
-                    // sized from the segment's exact pair count (k_describe) plus slack for repeated keys; a bucket
-                    // that still overflows makes the step redo itself with the counting pass
-                    std::vector<uint64_t> spairs(nsb);
-                    HIP_TRY(c, hipMemcpyAsync(spairs.data(), c->seg_pairs.p, (size_t)nsb * 8, hipMemcpyDeviceToHost, c->stream));
-                    HIP_TRY(c, hipMemcpyAsync(&n_dots, c->grand_total.as<uint64_t>() + 1, 8, hipMemcpyDeviceToHost, c->stream));
-                    HIP_TRY(c, hipStreamSynchronize(c->stream));
+                    // no counting pass: the hash spreads a segment's pairs evenly over its buckets, so each region is the
+                    // average plus room for repeated keys (all copies of a key share a bucket); a region that still
+                    // overflows makes the step redo itself with the counting pass
                     for (uint32_t s2 = 0; s2 < nsb; ++s2) {
-                        const uint64_t cap = spairs[s2] / NB1 + spairs[s2] / (NB1 * 12) + std::min<uint64_t>(4096, spairs[s2]);
-                        for (uint32_t b2 = 0; b2 < NB1; ++b2) {
-                            boff[(size_t)s2 * NB1 + b2] = total; total += cap; blim[(size_t)s2 * NB1 + b2] = total;
-                        }
+                        const uint64_t nbk = (uint64_t)bmask[s2] + 1u;
+                        const uint64_t avg = spairs[s2] / nbk;
+                        const uint64_t cap = avg + avg / 2 + std::min<uint64_t>(2048, spairs[s2]);
+                        for (uint64_t b2 = 0; b2 < nbk; ++b2) { boff[bbase[s2] + b2] = total; total += cap; }
                     }
                 }
-                boff[nbk] = total;
+                boff[nbk_total] = total;
                 if ((rc = ensure(c, c->rec_a, std::max<uint64_t>(total, 1) * 8))) return rc;
-                if ((rc = ensure(c, c->rec_b, std::max<uint64_t>(total, 1) * 8))) return rc;
-                HIP_TRY(c, hipMemcpyAsync(c->bucket_off.p, boff.data(), (nbk + 1) * 8, hipMemcpyHostToDevice, c->stream));
-                HIP_TRY(c, hipMemcpyAsync(c->bucket_lim.p, blim.data(), nbk * 8, hipMemcpyHostToDevice, c->stream));
-                HIP_TRY(c, hipMemcpyAsync(c->hist1.p, boff.data(), nbk * 8, hipMemcpyHostToDevice, c->stream));  // cursors
+                HIP_TRY(c, hipMemcpyAsync(c->bucket_off.p, boff.data(), ((size_t)nbk_total + 1) * 8, hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(c, hipMemsetAsync(c->cursor.p, 0, (size_t)std::max(nbk_total, 1u) * 4, c->stream));
                 {
                     Prof p(c, SAGE_K_PARTITION);
-                    k_key_partition<1><<<pgrid, PART_TILE, 0, c->stream>>>(c->desc.as<uint4>(), c->pool.as<uint32_t>(),
-                                                                     c->occ_tok.as<uint32_t>(), A.tok_w0, n_occ, S,
-                                                                     c->hist1.as<unsigned long long>(),
-                                                                     c->rec_a.as<unsigned long long>(),
-                                                                     c->bucket_lim.as<unsigned long long>(), c->flags.as<uint32_t>());
+                    k_key_partition3<1><<<tgrid, PART_THREADS, part_lds, c->stream>>>(
+                        c->desc.as<uint4>(), c->pool.as<uint32_t>(), c->occ_tok.as<uint32_t>(), A.tok_w0, PP,
+                        c->tile_tab.as<uint4>(), max_tiles, c->cursor.as<uint32_t>(), c->rec_a.as<unsigned long long>(),
+                        c->flags.as<uint32_t>());
                 }
                 {
                     Prof p(c, SAGE_K_MISC);
-                    k_key_partition_long<1><<<lgrid, 256, 0, c->stream>>>(
-                        c->desc.as<uint4>(), c->pool.as<uint32_t>(), c->occ_tok.as<uint32_t>(), A.tok_w0,
-                        c->long_list.as<uint32_t>(), c->long_count.as<uint32_t>(), S, c->hist1.as<unsigned long long>(),
-                        c->rec_a.as<unsigned long long>(), c->bucket_lim.as<unsigned long long>(), c->flags.as<uint32_t>());
+                    k_key_giant<1><<<ggrid, 256, 0, c->stream>>>(c->desc.as<uint4>(), c->pool.as<uint32_t>(),
+                                                                 c->occ_tok.as<uint32_t>(), A.tok_w0,
+                                                                 c->giant_list.as<uint32_t>(), c->giant_count.as<uint32_t>(), S, PP,
+                                                                 c->cursor.as<uint32_t>(), c->rec_a.as<unsigned long long>(),
+                                                                 c->flags.as<uint32_t>());
                 }
                 {
                     Prof p(c, SAGE_K_COUNT);
-                    const uint32_t dgrid = (uint32_t)std::min<size_t>(nbk, 256u * 4u);
-                    k_key_dedupe<<<dgrid, 256, 0, c->stream>>>(c->bucket_off.as<unsigned long long>(),
-                                                               c->hist1.as<unsigned long long>(), (uint32_t)nbk,
-                                                               c->rec_a.as<unsigned long long>(),
-                                                               c->rec_b.as<unsigned long long>(),
-                                                               c->stats.as<unsigned long long>(), c->flags.as<uint32_t>());
+                    const uint32_t dgrid = std::min<uint32_t>(std::max(nbk_total, 1u), (uint32_t)c->n_cu);
+                    k_key_dedupe3<<<dgrid, PART_THREADS, set_lds, c->stream>>>(c->bucket_off.as<unsigned long long>(),
+                                                                               c->cursor.as<uint32_t>(), nbk_total,
+                                                                               c->rec_a.as<unsigned long long>(),
+                                                                               c->stats.as<unsigned long long>(), c->flags.as<uint32_t>());
                 }
             } else {
-                // ---- v1: one distinct-key set per segment in HBM, sized from the exact pair count: load <= 0.5 ----
+                // ---- count mode 1: one distinct-key set per segment in HBM, sized from the exact pair count: load <= 0.5 ----
                 std::vector<uint64_t> sbase(nsb), smask(nsb), spairs(nsb);
                 HIP_TRY(c, hipMemcpyAsync(spairs.data(), c->seg_pairs.p, (size_t)nsb * 8, hipMemcpyDeviceToHost, c->stream));
                 HIP_TRY(c, hipMemcpyAsync(&n_dots, c->grand_total.as<uint64_t>() + 1, 8, hipMemcpyDeviceToHost, c->stream));
@@ -699,8 +740,9 @@ void sage_destroy(sage_ctx* c) {
     for (auto e : c->ev_free) (void)hipEventDestroy(e);
     DevBuf* all[] = {&c->buckets, &c->keys, &c->byte_id, &c->direct2, &c->bloom, &c->pmask, &c->pmask8, &c->corpus, &c->rem, &c->line_off, &c->emb, &c->M, &c->ntok,
                      &c->tokoff, &c->tile_sums, &c->grand_total, &c->tok_w0, &c->occ_pos, &c->set, &c->seg_line_rel,
-                     &c->seg_tok_off, &c->set_base, &c->set_mask, &c->seg_pairs, &c->desc, &c->gcache, &c->hist1, &c->bucket_off, &c->bucket_lim, &c->rec_a, &c->rec_b, &c->nocc, &c->occoff, &c->occ_tok,
-                     &c->np_ab, &c->dot_off, &c->dots, &c->pool, &c->pool_cursor, &c->emb32, &c->inexact, &c->inex_list, &c->inex_count, &c->long_list, &c->long_count, &c->w2v_counts, &c->w2v_keep, &c->w2v_dropped, &c->w2v_aprob, &c->w2v_aidx, &c->w2v_syn0, &c->w2v_syn1, &c->ex_ids, &c->ex_starts, &c->ex_widths, &c->loss,
+                     &c->seg_tok_off, &c->set_base, &c->set_mask, &c->seg_pairs, &c->desc, &c->gcache, &c->bucket_off, &c->rec_a, &c->nocc, &c->occoff, &c->occ_tok,
+                     &c->np_ab, &c->dot_off, &c->dots, &c->pool, &c->pool_cursor, &c->np_all, &c->pair_off, &c->seg_first_occ, &c->seg_tile_off,
+                     &c->seg_bucket_base, &c->seg_nbk_mask, &c->cursor, &c->giant_list, &c->giant_count, &c->tile_tab, &c->emb32, &c->inexact, &c->inex_list, &c->inex_count, &c->long_list, &c->long_count, &c->w2v_counts, &c->w2v_keep, &c->w2v_dropped, &c->w2v_aprob, &c->w2v_aidx, &c->w2v_syn0, &c->w2v_syn1, &c->ex_ids, &c->ex_starts, &c->ex_widths, &c->loss,
                      &c->occ, &c->hist, &c->stats, &c->flags};
     for (DevBuf* b : all) release(*b);
     (void)hipStreamDestroy(c->stream);

@@ -156,6 +156,8 @@ __device__ __forceinline__ uint32_t window_pairs(uint32_t pl_, uint32_t c_, uint
 template <bool LONG>
 __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* __restrict__ occ_tok, uint32_t n_occ,
                                                   SegPlan S, uint4* __restrict__ desc, uint32_t* __restrict__ npairs_ab,
+                                                  uint32_t* __restrict__ npairs_all /* ablated + base pairs; 0 for a giant */,
+                                                  uint32_t* __restrict__ giant_list, uint32_t* __restrict__ giant_count,
                                                   uint32_t* __restrict__ pool, uint32_t* __restrict__ pool_cursor,
                                                   uint32_t pool_cap, unsigned long long* __restrict__ seg_pairs,
                                                   unsigned long long* __restrict__ occ,
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
                     ++L;
                     return true;
                 });
-                is_long = !w.complete || w.m > 0xFFFu;
+                is_long = !w.complete || w.m > SAGE_INLINE_MAX_M;
             } else {
                 w = walk_occurrence(A, t, p0, ldx, [&](uint32_t) { ++L; return true; });
             }
@@ -236,6 +238,8 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
                         flags[FLAG_POOL_FULL] = 1;
                     }
                     hdr |= SAGE_DH_OVER;
+                    if ((unsigned long long)window_pairs(w.pl, w.k, w.pr) + window_pairs(w.pl, w.m, w.pr) > (unsigned long long)SAGE_PART_GIANT)
+                        hdr |= SAGE_DH_GIANT;
                     uint4* dst = desc + (size_t)o * 4;
                     dst[0] = make_uint4(hdr, at, w.k, w.m);
                     dst[1] = make_uint4(0, 0, 0, 0); dst[2] = make_uint4(0, 0, 0, 0); dst[3] = make_uint4(0, 0, 0, 0);
@@ -246,6 +250,9 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
                 n_wrows += L;
                 n_ab += ab_pairs;
                 npairs_ab[o] = ab_pairs;
+                const bool giant = LONG && my_pairs > (unsigned long long)SAGE_PART_GIANT;
+                npairs_all[o] = giant ? 0u : (uint32_t)my_pairs;
+                if (giant) giant_list[atomicAdd(giant_count, 1u)] = o;      // rare: a line of thousands of tokens
                 acc_add_u32<DESC_ACC_BITS>(occ_id, occ_n, occ, w.a);
                 const uint32_t kk = w.k < hist_len ? w.k : hist_len - 1u;
                 if (kk < 32u) atomicAdd(&lhist[kk], 1u); else atomicAdd(&hist[kk], 1ull);

@@ -1,22 +1,7 @@
-// Distinct (ablated, target, context) keys per count segment, v2: hash-partition the key stream into buckets that
-// fit an LDS set, then deduplicate each bucket on chip.  Everything is a coalesced stream over HBM; no global
-// atomics per key (v1 = one random 64-bit CAS per key into an HBM-resident set).
-//
-//   k_key_hist     keys regenerated from descriptors -> counts per (segment, coarse bucket)           [read desc]
-//   (host prefix sum of the 64 x n_seg counters)
-//   k_key_scatter  keys regenerated again -> written into their coarse bucket's region                 [read desc, write rec]
-//   k_key_dedupe   one block per coarse bucket: LDS histogram -> fine buckets (second buffer) -> LDS set per fine
-//                  bucket, counts new keys (weight 2, or 1 when target == context)                     [read rec x3, write rec]
+// Distinct (ablated, target, context) keys per count segment (utils.py:237,245 `len(triples)`): key generation from the
+// occurrence descriptors, the per-segment HBM sets (count mode 1) and the default partition + LDS dedupe (further down).
 #pragma once
 #include "sage_kernels2.h"
-
-#define NB1 64           // coarse buckets per count segment
-#define FINE_TARGET 1536 // records per fine bucket aimed at
-#define SET_SLOTS 4096   // LDS set capacity (u64 slots, 32 KiB)
-#define SET_FILL 2048    // at most this many records are offered to one set pass (load <= 0.5)
-#define NB2_MAX 256
-#define PART_TILE 256u  // occurrences per k_key_partition tile (one workgroup)
-#define UNR 8          // keys a thread keeps in flight in the streaming loops of k_key_dedupe
 
 // Calls f(lo, hi) for every position pair of the occurrence's two windows (model.py:115-136 via descriptors).
 // d = the 16 descriptor words in registers; long windows stream their ids from the pool.
@@ -62,10 +47,70 @@ __device__ __forceinline__ void keys_from_desc(const uint32_t (&d)[16], const ui
     }
 }
 
+// The inline occurrence as the partition kernel holds it between its two phases: descriptor words and the first
+// BASE_PF ids of the base window [t - pl, t + m + pr), fetched in ONE batch of loads (the loop form pays one memory
+// latency per window token).
+#define BASE_PF 8
+struct InlineOcc {
+    uint32_t d[16];
+    uint32_t base[BASE_PF];
+    uint32_t t, a;
+};
+__device__ __forceinline__ void load_inline(const uint4* __restrict__ desc, const uint32_t* __restrict__ occ_tok,
+                                            const uint32_t* __restrict__ tok_w0, uint32_t o, InlineOcc& x);
+template <class F>
+__device__ __forceinline__ void keys_from_inline(const InlineOcc& x, const uint32_t* __restrict__ tok_w0, F&& f) {
+    const Win w = win_decode(x.d[0], x.d[2], x.d[3]);
+    const uint32_t pl = w.pl, k = w.k, m = w.m, pr = w.pr, L = w.L;
+#pragma unroll
+    for (int j = 1; j < SAGE_DESC_MAXWIN; ++j) {
+        if ((uint32_t)j < L) {
+            const bool c = (uint32_t)j >= pl && (uint32_t)j < pl + k;
+            const bool c1 = (uint32_t)(j - 1) >= pl && (uint32_t)(j - 1) < pl + k;
+            if (c || c1) f(min(x.d[1 + j], x.d[j]), max(x.d[1 + j], x.d[j]));
+            if (j >= 2) {
+                const bool c2 = (uint32_t)(j - 2) >= pl && (uint32_t)(j - 2) < pl + k;
+                if (c || c2) f(min(x.d[1 + j], x.d[j - 1]), max(x.d[1 + j], x.d[j - 1]));
+            }
+        }
+    }
+    const uint32_t nb = pl + m + pr;      // base window tokens, centre [pl, pl + m)
+    uint32_t p1 = 0, p2 = 0;
+#pragma unroll
+    for (int i = 0; i < BASE_PF; ++i) {
+        if ((uint32_t)i < nb) {
+            const uint32_t id = x.base[i];
+            const bool c = (uint32_t)i >= pl && (uint32_t)i < pl + m;
+            if (i >= 1) { const bool c1 = (uint32_t)(i - 1) >= pl && (uint32_t)(i - 1) < pl + m; if (c || c1) f(min(id, p1), max(id, p1)); }
+            if (i >= 2) { const bool c2 = (uint32_t)(i - 2) >= pl && (uint32_t)(i - 2) < pl + m; if (c || c2) f(min(id, p2), max(id, p2)); }
+            p2 = p1; p1 = id;
+        }
+    }
+    for (uint32_t i = BASE_PF; i < nb; ++i) {        // a base span of more than 4 tokens: rare
+        const uint32_t id = SAGE_T_ID(tok_w0[x.t - pl + i]);
+        const bool c = i >= pl && i < pl + m;
+        { const bool c1 = (i - 1) >= pl && (i - 1) < pl + m; if (c || c1) f(min(id, p1), max(id, p1)); }
+        { const bool c2 = (i - 2) >= pl && (i - 2) < pl + m; if (c || c2) f(min(id, p2), max(id, p2)); }
+        p2 = p1; p1 = id;
+    }
+}
+
 __device__ __forceinline__ void load_desc(const uint4* __restrict__ desc, uint32_t o, uint32_t (&d)[16]) {
     const uint4 a = desc[(size_t)o * 4], b = desc[(size_t)o * 4 + 1], c = desc[(size_t)o * 4 + 2], e = desc[(size_t)o * 4 + 3];
     d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
     d[8] = c.x; d[9] = c.y; d[10] = c.z; d[11] = c.w; d[12] = e.x; d[13] = e.y; d[14] = e.z; d[15] = e.w;
+}
+
+__device__ __forceinline__ void load_inline(const uint4* __restrict__ desc, const uint32_t* __restrict__ occ_tok,
+                                            const uint32_t* __restrict__ tok_w0, uint32_t o, InlineOcc& x) {
+    load_desc(desc, o, x.d);
+    x.t = occ_tok[o];
+    const uint32_t pl = SAGE_DH_PL(x.d[0]);
+    const uint32_t nb = (x.d[0] & SAGE_DH_OVER) ? 0u : pl + SAGE_DH_M(x.d[0]) + SAGE_DH_PR(x.d[0]);
+#pragma unroll
+    for (int i = 0; i < BASE_PF; ++i) x.base[i] = (uint32_t)i < nb ? SAGE_T_ID(tok_w0[x.t - pl + (uint32_t)i]) : 0u;
+    x.a = (x.d[0] & SAGE_DH_OVER) ? SAGE_T_ID(tok_w0[x.t]) : x.base[pl < (uint32_t)BASE_PF ? pl : 0];
+    if (pl >= (uint32_t)BASE_PF) x.a = SAGE_T_ID(tok_w0[x.t]);
 }
 
 __device__ __forceinline__ uint64_t make_key(uint32_t a, uint32_t lo, uint32_t hi) {
@@ -96,97 +141,109 @@ __global__ __launch_bounds__(256) void k_count_sets(const uint4* __restrict__ de
     if ((threadIdx.x & 63u) == 0 && n_distinct) atomicAdd(&stats[STAT_DISTINCT], n_distinct);
 }
 
-// ---- passes 1 and 2: counts per (segment, coarse bucket), then the scatter ---------------------------------------
-// MODE 0: count into `counters`.  MODE 1: scatter into rec using `counters` as cursors (they start at each bucket's
-// base offset).  A tile of 256 consecutive occurrences touches at most two segments in practice; those go through
-// LDS counters and one global atomic per (tile, bucket); anything else takes one global atomic per key.
-template <int MODE>
-__global__ __launch_bounds__(PART_TILE) void k_key_partition(const uint4* __restrict__ desc, const uint32_t* __restrict__ pool,
-                                                       const uint32_t* __restrict__ occ_tok,
-                                                       const uint32_t* __restrict__ tok_w0, uint32_t n_occ, SegPlan S,
-                                                       unsigned long long* __restrict__ counters,
-                                                       unsigned long long* __restrict__ rec,
-                                                       const unsigned long long* __restrict__ limit, uint32_t* __restrict__ flags) {
-    // limit != nullptr (MODE 1 without a counting pass): bucket regions were sized from an estimate; a reservation that
-    // would run past limit[bucket] raises FLAG_BUCKET_OVERFLOW and writes nothing (the step is redone with exact sizes)
-    __shared__ unsigned int cnt[2][NB1];
-    __shared__ unsigned long long gbase[2][NB1];
-    const uint32_t n_round = (n_occ + PART_TILE - 1u) / PART_TILE * PART_TILE;
-    for (uint32_t base = blockIdx.x * PART_TILE; base < n_round; base += gridDim.x * PART_TILE) {
-        const uint32_t o = base + threadIdx.x;
-        if (threadIdx.x < 2 * NB1) cnt[threadIdx.x / NB1][threadIdx.x % NB1] = 0;
-        const uint32_t s0 = find_segment(S, occ_tok[base]);
-        uint32_t d[16];
-        const bool live = o < n_occ;
-        uint32_t seg = 0, a = 0, t = 0;
-        if (live) {
-            load_desc(desc, o, d);
-            t = occ_tok[o];
-            seg = find_segment(S, t);
-            a = SAGE_T_ID(tok_w0[t]);
+// =================================================================================================================
+// Distinct count, default back end: ONE partition level.  The key stream goes straight into buckets small enough for one
+// LDS set pass (<= PART_NBK_MAX buckets per count segment, ~8k records each), so the dedupe kernel reads every record
+// exactly once and writes nothing.  What makes a 2,048-way scatter write whole sectors is the size of the stage: a
+// workgroup gathers the keys of a TILE of occurrences (up to PART_STAGE = 16,384 records, 128 KiB of LDS), groups
+// them by bucket on chip and writes each bucket's run (8 records on average) with consecutive lanes.
+//   k_tile_plan        per count segment: first occurrence, number of tiles (host-free: the grid reads the total)
+//   k_key_partition3   persistent 1024-thread workgroups, one tile at a time:
+//                        count keys per bucket (LDS) -> scan -> reserve each bucket's range with one coalesced atomic
+//                        per bucket -> regenerate keys into their sorted place in the stage -> copy the stage out
+//   k_key_giant        occurrences with more than PART_GIANT position pairs (a line of thousands of tokens that never
+//                      rejoins): one workgroup each, one global atomic per key (they are rare)
+//   k_key_dedupe3      one workgroup per bucket: a 16,384-slot LDS set; the next bucket's records are loaded while
+//                      the current ones are inserted
+// Tiles are cut at multiples of PART_FILL position pairs inside a segment; every non-giant occurrence has at most
+// PART_GIANT pairs, so a tile never holds more than PART_FILL + PART_GIANT = PART_STAGE records.
+// =================================================================================================================
+#define PART_THREADS 1024u
+#define PART_STAGE 16384u
+#define PART_GIANT SAGE_PART_GIANT
+#define PART_FILL (PART_STAGE - PART_GIANT)
+#define PART_NBK_MAX 2048u
+#define PART_LONGS 512u          // long occurrences one tile can hold (each has > 15 pairs)
+#define PART_INVALID 0xFFFFFFFFu
+#define SET3_SLOTS 16384u        // 128 KiB LDS set
+#define SET3_FILL 10240u         // records offered to one set pass (load <= 0.625)
+
+struct PartPlan {
+    const uint32_t* pair_off;        // [n_occ + 1] exclusive scan of the per-occurrence pair counts (giants count 0)
+    const uint32_t* seg_first_occ;   // [n_seg + 1]
+    const uint32_t* seg_tile_off;    // [n_seg + 1] exclusive prefix of the tiles per segment
+    const uint32_t* seg_bucket_base; // [n_seg + 1] index of the segment's first bucket
+    const uint32_t* seg_nbk_mask;    // [n_seg] buckets of the segment - 1 (a power of two <= PART_NBK_MAX)
+    const unsigned long long* bucket_off;   // [n_buckets + 1] first record of every bucket's region
+    uint32_t n_seg;
+};
+
+// Per count segment: its first occurrence (occurrences are in token order) and its tile count.
+__global__ __launch_bounds__(256) void k_tile_plan(const uint32_t* __restrict__ occ_tok, uint32_t n_occ,
+                                                   const uint32_t* __restrict__ seg_tok_off, uint32_t n_seg,
+                                                   const uint32_t* __restrict__ pair_off,
+                                                   uint32_t* __restrict__ seg_first_occ, uint32_t* __restrict__ seg_tile_off) {
+    for (uint32_t s = threadIdx.x; s <= n_seg; s += 256u) {
+        const uint32_t t0 = seg_tok_off[s];
+        uint32_t lo = 0, hi = n_occ;           // first occurrence whose token is >= t0
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (occ_tok[mid] < t0) lo = mid + 1; else hi = mid;
         }
-        const bool local = live && (seg - s0) < 2u;
-        __syncthreads();
-        if (live) {
-            keys_from_desc<false>(d, pool, tok_w0, t, [&](uint32_t lo, uint32_t hi) {
-                const uint64_t key = make_key(a, lo, hi);
-                const uint32_t b1 = sage_key_hash_a(key) & (NB1 - 1);
-                if (local) atomicAdd(&cnt[seg - s0][b1], 1u);
-                else if (MODE == 0) atomicAdd(&counters[(size_t)seg * NB1 + b1], 1ull);
-                else {
-                    const unsigned long long at = atomicAdd(&counters[(size_t)seg * NB1 + b1], 1ull);
-                    if (!limit || at < limit[(size_t)seg * NB1 + b1]) rec[at] = key;
-                    else flags[FLAG_BUCKET_OVERFLOW] = 1;
-                }
-            });
+        seg_first_occ[s] = s == n_seg ? n_occ : lo;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (uint32_t s = 0; s < n_seg; ++s) {
+            seg_tile_off[s] = acc;
+            const uint32_t pairs = pair_off[seg_first_occ[s + 1]] - pair_off[seg_first_occ[s]];
+            acc += (pairs + PART_FILL - 1u) / PART_FILL;
         }
-        __syncthreads();
-        if (threadIdx.x < 2 * NB1) {
-            const uint32_t ls = threadIdx.x / NB1, b = threadIdx.x % NB1;
-            const uint32_t n = cnt[ls][b];
-            if (n && (s0 + ls) < S.n_seg) {
-                unsigned long long old = atomicAdd(&counters[(size_t)(s0 + ls) * NB1 + b], (unsigned long long)n);
-                if (MODE == 1 && limit && old + n > limit[(size_t)(s0 + ls) * NB1 + b]) { flags[FLAG_BUCKET_OVERFLOW] = 1; old = ~0ull; }
-                if (MODE == 1) gbase[ls][b] = old;
-            }
-            if (MODE == 1) cnt[ls][b] = 0;
-        }
-        if (MODE == 1) {
-            __syncthreads();
-            if (local) {
-                keys_from_desc<false>(d, pool, tok_w0, t, [&](uint32_t lo, uint32_t hi) {
-                    const uint64_t key = make_key(a, lo, hi);
-                    const uint32_t b1 = sage_key_hash_a(key) & (NB1 - 1);
-                    const uint32_t r = atomicAdd(&cnt[seg - s0][b1], 1u);
-                    const unsigned long long gb = gbase[seg - s0][b1];
-                    if (gb != ~0ull) rec[gb + r] = key;
-                });
-            }
-        }
-        __syncthreads();
+        seg_tile_off[n_seg] = acc;
     }
 }
 
-// ---- passes 1 and 2 for the long (pooled) occurrences: a WAVE per occurrence, lanes stride over the window --------
-// A wave takes LONG_CHUNK consecutive list entries, splits them into runs of one segment (nearly always a single
-// run: the list is in rough corpus order), counts the run's keys per bucket in its own LDS counters, reserves the
-// bucket ranges with one global atomic per non-empty bucket, and (MODE 1) walks the run again to write the keys.
-#define LONG_CHUNK 16
+// One thread per tile: its segment and occurrence range (binary searches that would otherwise stall a whole workgroup).
+__global__ __launch_bounds__(256) void k_tile_table(PartPlan P, uint32_t max_tiles, uint4* __restrict__ tile_tab) {
+    const uint32_t n_tiles = min(P.seg_tile_off[P.n_seg], max_tiles);
+    for (uint32_t tile = blockIdx.x * 256u + threadIdx.x; tile < n_tiles; tile += gridDim.x * 256u) {
+        uint32_t lo = 0, hi = P.n_seg;     // segment of the tile: largest s with seg_tile_off[s] <= tile
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (P.seg_tile_off[mid] <= tile) lo = mid; else hi = mid;
+        }
+        const uint32_t s = lo, j = tile - P.seg_tile_off[s];
+        const uint32_t o_a = P.seg_first_occ[s], o_b = P.seg_first_occ[s + 1];
+        const uint32_t p_lo = P.pair_off[o_a] + j * PART_FILL, p_hi = p_lo + PART_FILL;
+        // occurrences of the tile: those whose first pair lies in [p_lo, p_hi) (a giant counts no pairs, falls to
+        // whichever tile its offset lands in and is skipped there)
+        uint32_t a = o_a, b = o_b;
+        while (a < b) { const uint32_t mid = (a + b) >> 1; if (P.pair_off[mid] < p_lo) a = mid + 1; else b = mid; }
+        const uint32_t first = a;
+        b = o_b;
+        while (a < b) { const uint32_t mid = (a + b) >> 1; if (P.pair_off[mid] < p_hi) a = mid + 1; else b = mid; }
+        tile_tab[tile] = make_uint4(s, first, a, 0u);
+    }
+}
+
+// keys of one pooled occurrence, positions j = first, first + stride, ... (a wave, or a whole workgroup)
 template <class F>
-__device__ __forceinline__ void keys_of_long(const uint4* __restrict__ desc, const uint32_t* __restrict__ pool,
-                                             const uint32_t* __restrict__ tok_w0, uint32_t o, uint32_t t, uint32_t lane, F&& f) {
+__device__ __forceinline__ void keys_of_pooled(const uint4* __restrict__ desc, const uint32_t* __restrict__ pool,
+                                               const uint32_t* __restrict__ tok_w0, uint32_t o, uint32_t t, uint32_t first,
+                                               uint32_t stride, F&& f) {
     const uint4 h = desc[(size_t)o * 4];
     const Win w = win_decode(h.x, h.z, h.w);
     const uint32_t pl = w.pl, k = w.k, m = w.m, pr = w.pr, L = w.L;
     const uint32_t* ids = pool + h.y;
-    for (uint32_t j = lane; j < L; j += 64u) {
+    for (uint32_t j = first; j < L; j += stride) {
         const uint32_t id = ids[j];
         const bool c = j >= pl && j < pl + k;
         if (j >= 1u) { const uint32_t p1 = ids[j - 1]; const bool c1 = (j - 1) >= pl && (j - 1) < pl + k; if (c || c1) f(min(id, p1), max(id, p1)); }
         if (j >= 2u) { const uint32_t p2 = ids[j - 2]; const bool c2 = (j - 2) >= pl && (j - 2) < pl + k; if (c || c2) f(min(id, p2), max(id, p2)); }
     }
     const uint32_t w0 = t - pl, w1 = t + m + pr;  // base window tokens [w0, w1), centre [t, t+m)
-    for (uint32_t i = w0 + lane; i < w1; i += 64u) {
+    for (uint32_t i = w0 + first; i < w1; i += stride) {
         const uint32_t id = SAGE_T_ID(tok_w0[i]);
         const bool c = i >= t && i < t + m;
         if (i >= w0 + 1) { const uint32_t p1 = SAGE_T_ID(tok_w0[i - 1]); const bool c1 = (i - 1) >= t && (i - 1) < t + m; if (c || c1) f(min(id, p1), max(id, p1)); }
@@ -194,229 +251,250 @@ __device__ __forceinline__ void keys_of_long(const uint4* __restrict__ desc, con
     }
 }
 
+// MODE 0: count only (the exact-size pass: adds every tile's bucket counts to `cursor`).  MODE 1: scatter.
 template <int MODE>
-__global__ __launch_bounds__(256) void k_key_partition_long(const uint4* __restrict__ desc, const uint32_t* __restrict__ pool,
-                                                            const uint32_t* __restrict__ occ_tok,
-                                                            const uint32_t* __restrict__ tok_w0,
-                                                            const uint32_t* __restrict__ long_list,
-                                                            const uint32_t* __restrict__ long_count, SegPlan S,
-                                                            unsigned long long* __restrict__ counters,
-                                                            unsigned long long* __restrict__ rec,
-                                                            const unsigned long long* __restrict__ limit, uint32_t* __restrict__ flags) {
-    static_assert(NB1 == 64, "one lane per coarse bucket");
-    __shared__ unsigned int cnt[4][NB1];
-    __shared__ unsigned long long gbase[4][NB1];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t n = *long_count;
-    const uint32_t n_chunks = (n + LONG_CHUNK - 1) / LONG_CHUNK;
-    for (uint32_t chunk = blockIdx.x * 4u + wave; chunk < n_chunks; chunk += gridDim.x * 4u) {
-        const uint32_t e0 = chunk * LONG_CHUNK, e1 = min(n, e0 + LONG_CHUNK);
-        // lane i < LONG_CHUNK holds entry e0 + i: occurrence, token, segment
-        uint32_t my_o = 0, my_t = 0, my_seg = 0xFFFFFFFFu;
-        if (e0 + lane < e1) {
-            my_o = long_list[e0 + lane];
-            my_t = occ_tok[my_o];
-            my_seg = find_segment(S, my_t);
+__global__ __launch_bounds__(PART_THREADS) void k_key_partition3(const uint4* __restrict__ desc, const uint32_t* __restrict__ pool,
+                                                                 const uint32_t* __restrict__ occ_tok,
+                                                                 const uint32_t* __restrict__ tok_w0, PartPlan P,
+                                                                 const uint4* __restrict__ tile_tab, uint32_t max_tiles,
+                                                                 uint32_t* __restrict__ cursor /* [n_buckets] records placed so far */,
+                                                                 unsigned long long* __restrict__ rec, uint32_t* __restrict__ flags) {
+    extern __shared__ unsigned long long part_lds[];
+    unsigned long long* stage = part_lds;                                     // [PART_STAGE]
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(stage + PART_STAGE);          // [PART_NBK_MAX]
+    uint32_t* cstart = cnt + PART_NBK_MAX;                                    // [PART_NBK_MAX] (cnt + cstart: 64-bit deltas at copy-out)
+    uint32_t* gbase = cstart + PART_NBK_MAX;                                  // [PART_NBK_MAX]
+    uint32_t* longs = gbase + PART_NBK_MAX;                                   // [PART_LONGS]
+    uint32_t* misc = longs + PART_LONGS;                                      // [8]: tile scalars, wave sums
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n_tiles = min(P.seg_tile_off[P.n_seg], max_tiles);
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        if (tid == 0) misc[3] = 0u;     // long occurrences listed
+        for (uint32_t i = tid; i < PART_NBK_MAX; i += PART_THREADS) cnt[i] = 0u;
+        __syncthreads();
+        const uint4 tt = tile_tab[tile];
+        const uint32_t s = tt.x, o_lo = tt.y, o_hi = tt.z;
+        const uint32_t mask = P.seg_nbk_mask[s];
+        const uint32_t bbase = P.seg_bucket_base[s];
+        // ---- phase A: keys per bucket; pooled occurrences are set aside for the wave-per-occurrence loop.  The usual tile
+        // has fewer occurrences than the workgroup has threads: each thread then keeps its occurrence in registers for
+        // phase B instead of loading it again.
+        const bool one_round = o_hi - o_lo <= PART_THREADS;
+        InlineOcc X;
+        bool have = false;
+        for (uint32_t o = o_lo + tid; o < o_hi; o += PART_THREADS) {
+            load_inline(desc, occ_tok, tok_w0, o, X);
+            if (X.d[0] & SAGE_DH_GIANT) continue;                             // k_key_giant's
+            if (X.d[0] & SAGE_DH_OVER) {
+                const uint32_t at = atomicAdd(&misc[3], 1u);
+                if (at < PART_LONGS) longs[at] = o; else flags[FLAG_SET_OVERFLOW] = 1;   // cannot happen: > 15 pairs each
+                continue;
+            }
+            have = true;
+            const uint32_t a = X.a;
+            keys_from_inline(X, tok_w0, [&](uint32_t lo, uint32_t hi) {
+                atomicAdd(&cnt[sage_key_hash_a(make_key(a, lo, hi)) & mask], 1u);
+            });
         }
-        uint32_t e = e0;
-        while (e < e1) {
-            const uint32_t seg = __shfl(my_seg, (int)(e - e0), 64);
-            uint32_t f = e + 1;
-            while (f < e1 && __shfl(my_seg, (int)(f - e0), 64) == seg) ++f;
-            cnt[wave][lane] = 0;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            for (uint32_t g = e; g < f; ++g) {
-                const uint32_t o = __shfl(my_o, (int)(g - e0), 64), t = __shfl(my_t, (int)(g - e0), 64);
-                const uint32_t a = SAGE_T_ID(tok_w0[t]);
-                keys_of_long(desc, pool, tok_w0, o, t, lane, [&](uint32_t lo, uint32_t hi) {
-                    atomicAdd(&cnt[wave][sage_key_hash_a(make_key(a, lo, hi)) & (NB1 - 1)], 1u);
-                });
+        __syncthreads();
+        // pooled occurrences (~1.5 % of them): a wave each, so that their dependent loads (header -> pool ids) overlap
+        const uint32_t n_long = min(misc[3], PART_LONGS);
+        for (uint32_t q = tid >> 6; q < n_long; q += PART_THREADS / 64u) {
+            const uint32_t o = longs[q], t = occ_tok[o];
+            const uint32_t a = SAGE_T_ID(tok_w0[t]);
+            keys_of_pooled(desc, pool, tok_w0, o, t, tid & 63u, 64u, [&](uint32_t lo, uint32_t hi) {
+                atomicAdd(&cnt[sage_key_hash_a(make_key(a, lo, hi)) & mask], 1u);
+            });
+        }
+        __syncthreads();
+        // ---- exclusive scan of the bucket counts (2 per thread), bucket ranges reserved with coalesced atomics
+        {
+            const uint32_t c0 = cnt[2 * tid], c1 = cnt[2 * tid + 1];
+            const uint32_t v = c0 + c1;
+            uint32_t incl = v;
+            const uint32_t lane = tid & 63u, wave = tid >> 6;
+#pragma unroll
+            for (int dd = 1; dd < 64; dd <<= 1) {
+                const uint32_t nn = __shfl_up(incl, dd, 64);
+                if (lane >= (uint32_t)dd) incl += nn;
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            {
-                const uint32_t nb = cnt[wave][lane];
-                unsigned long long old = 0;
-                if (nb) old = atomicAdd(&counters[(size_t)seg * NB1 + lane], (unsigned long long)nb);
-                if (MODE == 1 && limit && nb && old + nb > limit[(size_t)seg * NB1 + lane]) { flags[FLAG_BUCKET_OVERFLOW] = 1; old = ~0ull; }
-                if (MODE == 1) { gbase[wave][lane] = old; cnt[wave][lane] = 0; }
-            }
+            uint32_t* wsum = misc + 8;      // [16] wave totals
+            if (lane == 63) wsum[wave] = incl;
+            __syncthreads();
+            uint32_t wbase = 0;
+            for (uint32_t ww = 0; ww < wave; ++ww) wbase += wsum[ww];
+            const uint32_t ex = wbase + incl - v;
+            cstart[2 * tid] = ex;
+            cstart[2 * tid + 1] = ex + c0;
+            if (tid == PART_THREADS - 1u) misc[4] = ex + v;      // records of the tile
+        }
+        __syncthreads();
+        for (uint32_t b = tid; b <= mask; b += PART_THREADS) {
+            const uint32_t n = cnt[b];
+            uint32_t old = 0;
+            if (n) old = atomicAdd(&cursor[bbase + b], n);
             if (MODE == 1) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                for (uint32_t g = e; g < f; ++g) {
-                    const uint32_t o = __shfl(my_o, (int)(g - e0), 64), t = __shfl(my_t, (int)(g - e0), 64);
-                    const uint32_t a = SAGE_T_ID(tok_w0[t]);
-                    keys_of_long(desc, pool, tok_w0, o, t, lane, [&](uint32_t lo, uint32_t hi) {
-                        const uint64_t key = make_key(a, lo, hi);
-                        const uint32_t b1 = sage_key_hash_a(key) & (NB1 - 1);
-                        const uint32_t r = atomicAdd(&cnt[wave][b1], 1u);
-                        const unsigned long long gb = gbase[wave][b1];
-                        if (gb != ~0ull) rec[gb + r] = key;
-                    });
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+                const unsigned long long cap = P.bucket_off[bbase + b + 1] - P.bucket_off[bbase + b];
+                if (n && (unsigned long long)old + n > cap) { flags[FLAG_BUCKET_OVERFLOW] = 1; old = PART_INVALID; }
+                gbase[b] = old;
+                cnt[b] = 0u;
             }
-            e = f;
         }
+        if (MODE == 0) { __syncthreads(); continue; }
+        __syncthreads();
+        // ---- phase B: the same keys again, each into its place in the stage
+        auto place = [&](const InlineOcc& x) {
+            const uint32_t a = x.a;
+            keys_from_inline(x, tok_w0, [&](uint32_t lo, uint32_t hi) {
+                const uint64_t key = make_key(a, lo, hi);
+                const uint32_t b = sage_key_hash_a(key) & mask;
+                const uint32_t at = cstart[b] + atomicAdd(&cnt[b], 1u);
+                if (at < PART_STAGE) stage[at] = key;
+            });
+        };
+        if (one_round) {
+            if (have) place(X);
+        } else {
+            for (uint32_t o = o_lo + tid; o < o_hi; o += PART_THREADS) {
+                load_inline(desc, occ_tok, tok_w0, o, X);
+                if (X.d[0] & SAGE_DH_OVER) continue;                          // pooled (loop below) or giant
+                place(X);
+            }
+        }
+        for (uint32_t q = tid >> 6; q < n_long; q += PART_THREADS / 64u) {
+            const uint32_t o = longs[q], t = occ_tok[o];
+            const uint32_t a = SAGE_T_ID(tok_w0[t]);
+            keys_of_pooled(desc, pool, tok_w0, o, t, tid & 63u, 64u, [&](uint32_t lo, uint32_t hi) {
+                const uint64_t key = make_key(a, lo, hi);
+                const uint32_t b = sage_key_hash_a(key) & mask;
+                const uint32_t at = cstart[b] + atomicAdd(&cnt[b], 1u);
+                if (at < PART_STAGE) stage[at] = key;
+            });
+        }
+        __syncthreads();
+        // ---- copy-out: consecutive lanes write one bucket's run.  dst = rec + delta[b] + e with delta[b] = the bucket's
+        // reserved start minus its start in the stage, kept as 64-bit words over the space of cnt and gbase
+        {
+            unsigned long long dl[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const uint32_t b = 2u * tid + (uint32_t)q;
+                const uint32_t gb = gbase[b];
+                dl[q] = (b <= mask && gb != PART_INVALID) ? P.bucket_off[bbase + b] + gb - cstart[b] : ~0ull;
+            }
+            __syncthreads();
+            unsigned long long* delta = reinterpret_cast<unsigned long long*>(cnt);     // [PART_NBK_MAX]: cnt + cstart space
+            delta[2u * tid] = dl[0];
+            delta[2u * tid + 1u] = dl[1];
+        }
+        __syncthreads();
+        const uint32_t n_rec = min(misc[4], PART_STAGE);
+        const unsigned long long* delta = reinterpret_cast<const unsigned long long*>(cnt);
+        for (uint32_t e = tid; e < n_rec; e += PART_THREADS) {
+            const uint64_t key = stage[e];
+            const unsigned long long dlt = delta[sage_key_hash_a(key) & mask];
+            if (dlt != ~0ull) rec[dlt + e] = key;
+        }
+        __syncthreads();
     }
 }
 
-// ---- pass 3: one block per coarse bucket ---------------------------------------------------------------------
-__device__ __forceinline__ uint32_t lds_set_insert(unsigned long long* set, uint64_t key, uint32_t* flags) {
-    uint32_t s = sage_key_hash_b(key) & (SET_SLOTS - 1);
-    for (uint32_t probes = 0; probes < SET_SLOTS; ++probes) {
+// Giant occurrences: one workgroup each, one global atomic per key.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_key_giant(const uint4* __restrict__ desc, const uint32_t* __restrict__ pool,
+                                                   const uint32_t* __restrict__ occ_tok, const uint32_t* __restrict__ tok_w0,
+                                                   const uint32_t* __restrict__ giant_list, const uint32_t* __restrict__ giant_count,
+                                                   SegPlan S, PartPlan P, uint32_t* __restrict__ cursor,
+                                                   unsigned long long* __restrict__ rec, uint32_t* __restrict__ flags) {
+    const uint32_t n = *giant_count;
+    for (uint32_t g = blockIdx.x; g < n; g += gridDim.x) {
+        const uint32_t o = giant_list[g], t = occ_tok[o];
+        const uint32_t s = find_segment(S, t);
+        const uint32_t mask = P.seg_nbk_mask[s], bbase = P.seg_bucket_base[s];
+        const uint32_t a = SAGE_T_ID(tok_w0[t]);
+        keys_of_pooled(desc, pool, tok_w0, o, t, threadIdx.x, 256u, [&](uint32_t lo, uint32_t hi) {
+            const uint64_t key = make_key(a, lo, hi);
+            const uint32_t b = bbase + (sage_key_hash_a(key) & mask);
+            const uint32_t at = atomicAdd(&cursor[b], 1u);
+            if (MODE == 1) {
+                if ((unsigned long long)at < P.bucket_off[b + 1] - P.bucket_off[b]) rec[P.bucket_off[b] + at] = key;
+                else flags[FLAG_BUCKET_OVERFLOW] = 1;
+            }
+        });
+    }
+}
+
+// (Measured alternatives, all slower on the bench corpus at 12.4 ms for this kernel: every record of a thread probing in
+// the same round, 17.5 ms; lanes that move on to their next record as soon as a probe ends, 20.8 ms; a set split into
+// low words claimed by a 32-bit compare-and-swap and high words stored afterwards, 15.7 ms.  Without the insertions the
+// kernel takes 4.5 ms: it is bound by LDS atomic throughput.)
+__device__ __forceinline__ uint32_t lds_set3_insert(unsigned long long* set, uint64_t key, uint32_t* flags) {
+    uint32_t s = sage_key_hash_b(key) & (SET3_SLOTS - 1u);
+    for (uint32_t probes = 0; probes < SET3_SLOTS; ++probes) {
         const unsigned long long old = atomicCAS(&set[s], (unsigned long long)SAGE_SET_EMPTY, (unsigned long long)key);
         if (old == SAGE_SET_EMPTY) return ((uint32_t)(key >> 20) & SAGE_ID_MASK) == ((uint32_t)key & SAGE_ID_MASK) ? 1u : 2u;
         if (old == key) return 0u;
-        s = (s + 1) & (SET_SLOTS - 1);
+        s = (s + 1u) & (SET3_SLOTS - 1u);
     }
     flags[FLAG_SET_OVERFLOW] = 1;
     return 0u;
 }
 
-__global__ __launch_bounds__(256) void k_key_dedupe(const unsigned long long* __restrict__ bucket_off /* start of every bucket */,
-                                                    const unsigned long long* __restrict__ bucket_end /* cursors after the scatter */,
-                                                    uint32_t n_buckets, const unsigned long long* __restrict__ rec_in,
-                                                    unsigned long long* __restrict__ rec_tmp,
-                                                    unsigned long long* __restrict__ stats, uint32_t* __restrict__ flags) {
-    __shared__ unsigned long long set[SET_SLOTS];
-    __shared__ unsigned int hist2[NB2_MAX];
-    __shared__ unsigned int offs2[NB2_MAX + 1];
-    __shared__ unsigned int wsum[4];
-    __shared__ unsigned int chist[NB2_MAX], cstart[NB2_MAX], gpos[NB2_MAX];
+#define DD3_UNR 8   // records a thread holds of one bucket (8 x 1024 = the usual bucket in one round)
+__global__ __launch_bounds__(PART_THREADS) void k_key_dedupe3(const unsigned long long* __restrict__ bucket_off,
+                                                              const uint32_t* __restrict__ cursor, uint32_t n_buckets,
+                                                              const unsigned long long* __restrict__ rec,
+                                                              unsigned long long* __restrict__ stats, uint32_t* __restrict__ flags) {
+    extern __shared__ unsigned long long set3[];
     unsigned long long n_distinct = 0;
-    for (uint32_t bk = blockIdx.x; bk < n_buckets; bk += gridDim.x) {
-        const unsigned long long o0 = bucket_off[bk];
-        const uint32_t cnt = (uint32_t)min(bucket_end[bk] - o0, bucket_off[bk + 1] - o0);   // (an overflowed bucket is clamped)
+    const uint32_t tid = threadIdx.x;
+    // software pipeline over the workgroup's buckets: the records of bucket i+1 and the size and place of bucket i+2
+    // are loaded while bucket i is inserted, so no global latency is exposed between buckets
+    uint64_t nx[DD3_UNR];
+    auto meta = [&](uint32_t b, uint32_t& cnt, unsigned long long& off) {
+        cnt = 0; off = 0;
+        if (b >= n_buckets) return;
+        off = bucket_off[b];
+        const unsigned long long cap = bucket_off[b + 1] - off;
+        cnt = (uint32_t)min((unsigned long long)cursor[b], cap);     // (an overflowed bucket is clamped; the step is redone)
+    };
+    auto fetch = [&](uint32_t cnt, unsigned long long off) {
+        const unsigned long long* in = rec + off;
+#pragma unroll
+        for (int u = 0; u < DD3_UNR; ++u) nx[u] = (tid + PART_THREADS * u) < cnt ? in[tid + PART_THREADS * u] : SAGE_SET_EMPTY;
+    };
+    uint32_t bk = blockIdx.x;
+    uint32_t cnt0, cnt1, cnt2;
+    unsigned long long off0, off1, off2;
+    meta(bk, cnt0, off0);
+    meta(bk + gridDim.x, cnt1, off1);
+    fetch(cnt0, off0);
+    for (; bk < n_buckets; bk += gridDim.x) {
+        uint64_t cur[DD3_UNR];
+#pragma unroll
+        for (int u = 0; u < DD3_UNR; ++u) cur[u] = nx[u];
+        meta(bk + 2u * gridDim.x, cnt2, off2);
+        fetch(cnt1, off1);                              // the next bucket's records travel while this one is inserted
+        const uint32_t cnt = cnt0;
+        const unsigned long long* in = rec + off0;
+        cnt0 = cnt1; off0 = off1; cnt1 = cnt2; off1 = off2;
         if (cnt == 0) continue;
-        const unsigned long long* in = rec_in + o0;
-        unsigned long long* tmp = rec_tmp + o0;
-        uint32_t nb2 = 1;
-        while (nb2 < NB2_MAX && (uint64_t)nb2 * FINE_TARGET < cnt) nb2 <<= 1;
-        const unsigned long long* src = in;
-        __syncthreads();
-        if (nb2 > 1) {
-            // fine partition inside the block: histogram, exclusive scan, scatter into tmp
-            for (uint32_t i = threadIdx.x; i < nb2; i += 256) hist2[i] = 0;
+        const uint32_t passes = (cnt + SET3_FILL - 1u) / SET3_FILL;
+        for (uint32_t p = 0; p < passes; ++p) {
             __syncthreads();
-            for (uint32_t i0 = threadIdx.x; i0 < cnt; i0 += 256 * UNR) {
-                uint64_t kk[UNR];
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) kk[u] = (i0 + 256u * u) < cnt ? in[i0 + 256u * u] : 0ull;
-#pragma unroll
-                for (int u = 0; u < UNR; ++u)
-                    if ((i0 + 256u * u) < cnt) atomicAdd(&hist2[(sage_key_hash_a(kk[u]) >> 6) & (nb2 - 1)], 1u);
-            }
+            for (uint32_t i = tid; i < SET3_SLOTS; i += PART_THREADS) set3[i] = SAGE_SET_EMPTY;
             __syncthreads();
-            {   // exclusive scan of up to 256 counters by the 256 threads
-                const uint32_t v = threadIdx.x < nb2 ? hist2[threadIdx.x] : 0u;
-                uint32_t incl = v;
-                const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 #pragma unroll
-                for (int dd = 1; dd < 64; dd <<= 1) {
-                    const uint32_t nn = __shfl_up(incl, dd, 64);
-                    if (lane >= (uint32_t)dd) incl += nn;
-                }
-                if (lane == 63) wsum[wave] = incl;
-                __syncthreads();
-                uint32_t wbase = 0;
-                for (uint32_t ww = 0; ww < wave; ++ww) wbase += wsum[ww];
-                if (threadIdx.x < nb2) { offs2[threadIdx.x] = wbase + incl - v; hist2[threadIdx.x] = wbase + incl - v; }
-                if (threadIdx.x == 0) offs2[nb2] = cnt;
-            }
-            __syncthreads();
-            // Scatter through LDS, 2,048 records at a time: the chunk is grouped by fine bucket on chip (the dedupe set's
-            // memory is free at this point) and each bucket's run leaves as consecutive 8-byte stores, so HBM sees whole
-            // sectors instead of 256 interleaved streams of partial-line writes.
-            unsigned long long* stage = set;                               // 2,048 x 8 B
-            unsigned short* stage_fb = reinterpret_cast<unsigned short*>(set + 256 * UNR);   // 2,048 x 2 B
-            for (uint32_t c0 = 0; c0 < cnt; c0 += 256 * UNR) {
-                uint64_t kk[UNR];
-                uint32_t fbk[UNR], rk[UNR];
-                if (threadIdx.x < nb2) chist[threadIdx.x] = 0;
-                __syncthreads();
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const uint32_t i = c0 + threadIdx.x + 256u * u;
-                    kk[u] = i < cnt ? in[i] : 0ull;
-                }
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const uint32_t i = c0 + threadIdx.x + 256u * u;
-                    fbk[u] = (sage_key_hash_a(kk[u]) >> 6) & (nb2 - 1);
-                    rk[u] = i < cnt ? atomicAdd(&chist[fbk[u]], 1u) : 0u;
-                }
-                __syncthreads();
-                {   // exclusive scan of the chunk histogram; global base of every run
-                    const uint32_t vv = threadIdx.x < nb2 ? chist[threadIdx.x] : 0u;
-                    uint32_t incl = vv;
-                    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-#pragma unroll
-                    for (int dd = 1; dd < 64; dd <<= 1) {
-                        const uint32_t nn = __shfl_up(incl, dd, 64);
-                        if (lane >= (uint32_t)dd) incl += nn;
-                    }
-                    if (lane == 63) wsum[wave] = incl;
-                    __syncthreads();
-                    uint32_t wbase = 0;
-                    for (uint32_t ww = 0; ww < wave; ++ww) wbase += wsum[ww];
-                    if (threadIdx.x < nb2) {
-                        cstart[threadIdx.x] = wbase + incl - vv;
-                        gpos[threadIdx.x] = hist2[threadIdx.x];
-                        hist2[threadIdx.x] += vv;
-                    }
-                }
-                __syncthreads();
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                    const uint32_t i = c0 + threadIdx.x + 256u * u;
-                    if (i < cnt) {
-                        const uint32_t at = cstart[fbk[u]] + rk[u];
-                        stage[at] = kk[u];
-                        stage_fb[at] = (unsigned short)fbk[u];
-                    }
-                }
-                __syncthreads();
-                const uint32_t nchunk = min(256u * UNR, cnt - c0);
-                for (uint32_t e = threadIdx.x; e < nchunk; e += 256u) {
-                    const uint32_t fb = stage_fb[e];
-                    tmp[gpos[fb] + (e - cstart[fb])] = stage[e];
-                }
-                __syncthreads();
-            }
-            __threadfence_block();
-            __syncthreads();
-            src = tmp;
-        } else {
-            if (threadIdx.x == 0) { offs2[0] = 0; offs2[1] = cnt; }
-            __syncthreads();
-        }
-        for (uint32_t fb = 0; fb < nb2; ++fb) {
-            const uint32_t f0 = offs2[fb], fn = offs2[fb + 1] - f0;
-            if (fn == 0) continue;
-            const uint32_t passes = (fn + SET_FILL - 1) / SET_FILL;
-            for (uint32_t p = 0; p < passes; ++p) {
-                for (uint32_t i = threadIdx.x; i < SET_SLOTS; i += 256) set[i] = SAGE_SET_EMPTY;
-                __syncthreads();
-                for (uint32_t i0 = threadIdx.x; i0 < fn; i0 += 256 * UNR) {
-                    uint64_t kk[UNR];
-#pragma unroll
-                    for (int u = 0; u < UNR; ++u) kk[u] = (i0 + 256u * u) < fn ? src[f0 + i0 + 256u * u] : 0ull;
-#pragma unroll
-                    for (int u = 0; u < UNR; ++u)
-                        if ((i0 + 256u * u) < fn) {
-                            if (passes == 1 || (sage_key_hash_a(kk[u]) >> 14) % passes == p)
-                                n_distinct += lds_set_insert(set, kk[u], flags);
-                        }
-                }
-                __syncthreads();
+            for (int u = 0; u < DD3_UNR; ++u)
+                if (cur[u] != SAGE_SET_EMPTY && (passes == 1u || (sage_key_hash_a(cur[u]) >> 14) % passes == p))
+                    n_distinct += lds_set3_insert(set3, cur[u], flags);
+            for (uint32_t i = tid + PART_THREADS * DD3_UNR; i < cnt; i += PART_THREADS) {   // an oversized bucket's tail
+                const uint64_t k = in[i];
+                if (passes == 1u || (sage_key_hash_a(k) >> 14) % passes == p) n_distinct += lds_set3_insert(set3, k, flags);
             }
         }
     }
 #pragma unroll
     for (int dd = 32; dd >= 1; dd >>= 1) n_distinct += __shfl_down(n_distinct, dd, 64);
-    if ((threadIdx.x & 63u) == 0 && n_distinct) atomicAdd(&stats[STAT_DISTINCT], n_distinct);
+    if ((tid & 63u) == 0 && n_distinct) atomicAdd(&stats[STAT_DISTINCT], n_distinct);
 }

@@ -49,7 +49,7 @@ def test_tokenize_golden(tag):
 
 
 def _check_step(eng, bounds, want_tokens, want_triples, want_losses, want_sizes, want_occ=None, abs_scale=None):
-    for mode in (0, 1):   # both distinct-count back ends: LDS partition/dedupe and HBM sets
+    for mode in (0, 1):   # both distinct-count back ends: one-level partition + LDS dedupe, per-segment HBM sets
         eng.set_count_mode(mode)
         _check_step_once(eng, bounds, want_tokens, want_triples, want_losses, want_sizes, want_occ, abs_scale)
     eng.set_count_mode(0)
