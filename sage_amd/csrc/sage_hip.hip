@@ -90,7 +90,7 @@ struct sage_ctx {
 
     // scratch (grow-only; nothing is allocated in the steady state)
     DevBuf M, ntok, tokoff, tile_sums, grand_total, tok_w0, occ_pos, set, seg_line_rel, seg_tok_off, set_base, set_mask, seg_pairs, desc, gcache, bucket_off, rec_a,
-        nocc, occoff, occ_tok, np_ab, dot_off, dots, pool, pool_cursor,
+        nocc, occoff, occ_tok, occ_a, exact_list, exact_count, np_ab, dot_off, dots, pool, pool_cursor,
         np_all, pair_off, seg_first_occ, seg_tile_off, seg_bucket_base, seg_nbk_mask, cursor, giant_list, giant_count, tile_tab;
     int pool_factor = 8;  // id-pool words per occurrence (grown on overflow)
     bool exact_buckets = false;   // v2 count: size the key buckets with a counting pass instead of the estimate
@@ -322,8 +322,8 @@ void launch_pairs(sage_ctx* c, const T* emb, const uint32_t* tok_w0, uint32_t n_
 }
 
 template <int G, int EPL, typename T>
-void launch_dots(sage_ctx* c, const T* emb, uint32_t n_occ, bool listed) {
-    Prof p(c, listed ? SAGE_K_FIX : SAGE_K_SCORE);
+void launch_dots(sage_ctx* c, const T* emb, uint32_t n_occ, const uint32_t* list, const uint32_t* list_count, int cls) {
+    Prof p(c, cls);
     // persistent: exactly as many workgroups as the chip holds at once (a partial second round would double the time)
     static std::atomic<int> cached{0};   // per instantiation; the same for every gfx950 device
     int per_cu = cached.load(std::memory_order_relaxed);
@@ -335,8 +335,7 @@ void launch_dots(sage_ctx* c, const T* emb, uint32_t n_occ, bool listed) {
     const uint32_t grid = std::min<uint32_t>(cdiv(n_occ, 256 / G), (uint32_t)c->n_cu * (uint32_t)std::max(per_cu, 1));
     k_dots<G, EPL, T, 5><<<grid, 256, 0, c->stream>>>(
         c->desc.as<uint4>(), c->pool.as<uint32_t>(), n_occ, c->dot_off.as<uint32_t>(), emb, (uint32_t)c->emb_rows,
-        (uint32_t)c->dp, c->dots.as<double>(), c->flags.as<uint32_t>(),
-        listed ? c->inex_list.as<uint32_t>() : nullptr, listed ? c->inex_count.as<uint32_t>() : nullptr);
+        (uint32_t)c->dp, c->dots.as<double>(), c->flags.as<uint32_t>(), list, list_count);
 }
 
 // instantiation per padded row width: float32 rows are whole 16-byte loads of 4 elements, float64 rows of 2
@@ -359,37 +358,36 @@ void launch_dots(sage_ctx* c, const T* emb, uint32_t n_occ, bool listed) {
     default: FN<64, 8>(__VA_ARGS__); break;              \
     }
 
-// Scoring of one batch.  float32 row storage: pair cache and window dots from the float32 copy (rows it cannot hold
-// are NaN there); token quads that touch such a row are recomputed from the float64 matrix (bitmap test); k_logsig
-// lists the occurrences whose sum came out NaN, and their dots and sums are redone from the float64 matrix.
+// Scoring of one batch (compute_losses, utils.py:125-138).  Base windows: pair cache (k_pair_cache).  Ablated windows:
+// dot products (k_dots), then log-sigmoid, base-window range sums and accumulation per ablated id (k_logsig).
+// float32 row storage: k_describe has split the occurrences into those whose window rows the float32 copy holds exactly
+// (their dots come from it) and the others (their dots come from the float64 matrix), so neither pass gathers rows for
+// the other; token quads of the pair cache that touch such a row are recomputed from the float64 matrix (bitmap test).
 void launch_score(sage_ctx* c, const uint32_t* tok_w0, uint32_t n_tok, uint32_t n_occ) {
     const double* e64 = c->emb.as<double>();
     const float* e32 = c->emb32.as<float>();
-    const bool fix = c->use_f32 && c->n_inexact > 0;
+    const bool split = c->use_f32 && c->n_inexact > 0;
     if (c->use_f32) {
         SAGE_BY_WIDTH_F32(launch_pairs, c, e32, tok_w0, n_tok, false)
-        if (fix) { SAGE_BY_WIDTH_F64(launch_pairs, c, e64, tok_w0, n_tok, true) }
-        SAGE_BY_WIDTH_F32(launch_dots, c, e32, n_occ, false)
+        if (split) { SAGE_BY_WIDTH_F64(launch_pairs, c, e64, tok_w0, n_tok, true) }
     } else {
         SAGE_BY_WIDTH_F64(launch_pairs, c, e64, tok_w0, n_tok, false)
-        SAGE_BY_WIDTH_F64(launch_dots, c, e64, n_occ, false)
+    }
+    if (!c->use_f32) {
+        SAGE_BY_WIDTH_F64(launch_dots, c, e64, n_occ, nullptr, nullptr, SAGE_K_SCORE)
+    } else if (!split) {
+        SAGE_BY_WIDTH_F32(launch_dots, c, e32, n_occ, nullptr, nullptr, SAGE_K_SCORE)
+    } else {
+        SAGE_BY_WIDTH_F32(launch_dots, c, e32, n_occ, c->exact_list.as<uint32_t>(), c->exact_count.as<uint32_t>(), SAGE_K_SCORE)
+        SAGE_BY_WIDTH_F64(launch_dots, c, e64, n_occ, c->inex_list.as<uint32_t>(), c->inex_count.as<uint32_t>(), SAGE_K_FIX)
     }
     {
         Prof p(c, SAGE_K_LOGSIG);
         const uint32_t grid = std::min<uint32_t>(cdiv(n_occ, LOGSIG_TILE), 256u * 8u);
-        k_logsig<<<grid, 256, 0, c->stream>>>(c->desc.as<uint4>(), c->occ_tok.as<uint32_t>(), tok_w0, n_occ,
+        k_logsig<<<grid, 256, 0, c->stream>>>(c->desc.as<uint4>(), c->occ_tok.as<uint32_t>(), c->occ_a.as<uint32_t>(), n_occ,
                                               c->dot_off.as<uint32_t>(), c->dots.as<double>(), c->gcache.as<double2>(),
-                                              c->loss.as<double>(), fix ? c->inex_list.as<uint32_t>() : nullptr,
-                                              c->inex_count.as<uint32_t>());
-    }
-    if (fix) {
-        SAGE_BY_WIDTH_F64(launch_dots, c, e64, n_occ, true)
-        Prof p(c, SAGE_K_FIX);
-        const uint32_t grid = std::min<uint32_t>(cdiv(n_occ, 32), 256u * 8u);
-        k_logsig_list<<<grid, 256, 0, c->stream>>>(c->desc.as<uint4>(), c->occ_tok.as<uint32_t>(), tok_w0,
-                                                   c->inex_list.as<uint32_t>(), c->inex_count.as<uint32_t>(),
-                                                   c->dot_off.as<uint32_t>(), c->dots.as<double>(), c->gcache.as<double2>(),
-                                                   c->loss.as<double>(), c->stats.as<unsigned long long>());
+                                              c->loss.as<double>(), split ? c->inex_count.as<uint32_t>() : nullptr,
+                                              c->stats.as<unsigned long long>());
     }
 }
 
@@ -467,6 +465,7 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
             if ((rc = ensure(c, c->seg_pairs, (size_t)nsb * 8))) return rc;
             if ((rc = ensure(c, c->desc, (size_t)n_occ * SAGE_DESC_WORDS * 4))) return rc;
             if ((rc = ensure(c, c->gcache, (size_t)n_tok * 16))) return rc;
+            if ((rc = ensure(c, c->occ_a, (size_t)n_occ * 4))) return rc;
             if ((rc = ensure(c, c->np_ab, (size_t)n_occ * 4))) return rc;
             if ((rc = ensure(c, c->dot_off, ((size_t)n_occ + 1) * 4))) return rc;
             // never smaller than the longest possible window (<= pads + one id per byte of a line), so that a window
@@ -476,11 +475,14 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
             if ((rc = ensure(c, c->pool, pool_cap * 4))) return rc;
             HIP_TRY(c, hipMemsetAsync(c->seg_pairs.p, 0, (size_t)nsb * 8, c->stream));
             HIP_TRY(c, hipMemsetAsync(c->pool_cursor.p, 0, 4, c->stream));
-            const bool fix_pass = c->use_f32 && c->n_inexact > 0;
-            if (fix_pass) {
+            const bool split = c->use_f32 && c->n_inexact > 0;
+            if (split) {
                 if ((rc = ensure(c, c->inex_list, (size_t)n_occ * 4))) return rc;
+                if ((rc = ensure(c, c->exact_list, (size_t)n_occ * 4))) return rc;
                 if ((rc = ensure(c, c->inex_count, 4))) return rc;
+                if ((rc = ensure(c, c->exact_count, 4))) return rc;
                 HIP_TRY(c, hipMemsetAsync(c->inex_count.p, 0, 4, c->stream));
+                HIP_TRY(c, hipMemsetAsync(c->exact_count.p, 0, 4, c->stream));
             }
             SegPlan S{c->seg_tok_off.as<uint32_t>(), c->set_base.as<uint64_t>(), c->set_mask.as<uint64_t>(), nsb};
             const uint32_t cgrid = std::min<uint32_t>(cdiv(n_occ, 256), 256u * 16u);
@@ -493,29 +495,25 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
             if ((rc = ensure(c, c->pair_off, ((size_t)n_occ + 1) * 4))) return rc;
             HIP_TRY(c, hipMemsetAsync(c->long_count.p, 0, 4, c->stream));
             HIP_TRY(c, hipMemsetAsync(c->giant_count.p, 0, 4, c->stream));
+            const DescribeArgs DA{c->desc.as<uint4>(), c->occ_a.as<uint32_t>(), c->np_ab.as<uint32_t>(), c->np_all.as<uint32_t>(),
+                                  c->giant_list.as<uint32_t>(), c->giant_count.as<uint32_t>(),
+                                  c->pool.as<uint32_t>(), c->pool_cursor.as<uint32_t>(), (uint32_t)pool_cap,
+                                  c->seg_pairs.as<unsigned long long>(), c->occ.as<unsigned long long>(),
+                                  c->hist.as<unsigned long long>(), (uint32_t)hist_len, c->stats.as<unsigned long long>(),
+                                  c->flags.as<uint32_t>(), c->long_list.as<uint32_t>(), c->long_count.as<uint32_t>(),
+                                  split ? c->inexact.as<uint32_t>() : nullptr,
+                                  c->exact_list.as<uint32_t>(), c->exact_count.as<uint32_t>(),
+                                  c->inex_list.as<uint32_t>(), c->inex_count.as<uint32_t>()};
             {
                 Prof p(c, SAGE_K_DESCRIBE);
-                k_describe<false><<<cgrid, 256, 0, c->stream>>>(
-                    A, c->occ_tok.as<uint32_t>(), n_occ, S, c->desc.as<uint4>(), c->np_ab.as<uint32_t>(),
-                    c->np_all.as<uint32_t>(), c->giant_list.as<uint32_t>(), c->giant_count.as<uint32_t>(),
-                    c->pool.as<uint32_t>(), c->pool_cursor.as<uint32_t>(), (uint32_t)pool_cap,
-                    c->seg_pairs.as<unsigned long long>(), c->occ.as<unsigned long long>(),
-                    c->hist.as<unsigned long long>(), (uint32_t)hist_len, c->stats.as<unsigned long long>(),
-                    c->flags.as<uint32_t>(), c->long_list.as<uint32_t>(), c->long_count.as<uint32_t>());
+                k_describe<false><<<cgrid, 256, 0, c->stream>>>(A, c->occ_tok.as<uint32_t>(), n_occ, S, DA);
             }
             {
                 Prof p(c, SAGE_K_MISC);   // the long-occurrence kernels are accounted under "misc"
-                k_describe<true><<<lgrid, 256, 0, c->stream>>>(
-                    A, c->occ_tok.as<uint32_t>(), n_occ, S, c->desc.as<uint4>(), c->np_ab.as<uint32_t>(),
-                    c->np_all.as<uint32_t>(), c->giant_list.as<uint32_t>(), c->giant_count.as<uint32_t>(),
-                    c->pool.as<uint32_t>(), c->pool_cursor.as<uint32_t>(), (uint32_t)pool_cap,
-                    c->seg_pairs.as<unsigned long long>(), c->occ.as<unsigned long long>(),
-                    c->hist.as<unsigned long long>(), (uint32_t)hist_len, c->stats.as<unsigned long long>(),
-                    c->flags.as<uint32_t>(), c->long_list.as<uint32_t>(), c->long_count.as<uint32_t>());
+                k_describe<true><<<lgrid, 256, 0, c->stream>>>(A, c->occ_tok.as<uint32_t>(), n_occ, S, DA);
             }
-            // offsets of every occurrence's ablated-window dots; grand_total[1] is reused for the dot total
+            // offsets of every occurrence's ablated-window dots; grand_total[1] holds the dot total
             if ((rc = scan_u32(c, c->np_ab.as<uint32_t>(), n_occ, c->dot_off.as<uint32_t>(), c->grand_total.as<uint64_t>() + 1))) return rc;
-
             uint64_t n_dots = 0;
             if (c->count_mode == 0 && !c->count_fallback) {
                 // ---- default: one partition level into LDS-set-sized buckets, every record read once (sage_kernels3.h) ----
@@ -741,7 +739,7 @@ void sage_destroy(sage_ctx* c) {
     DevBuf* all[] = {&c->buckets, &c->keys, &c->byte_id, &c->direct2, &c->bloom, &c->pmask, &c->pmask8, &c->corpus, &c->rem, &c->line_off, &c->emb, &c->M, &c->ntok,
                      &c->tokoff, &c->tile_sums, &c->grand_total, &c->tok_w0, &c->occ_pos, &c->set, &c->seg_line_rel,
                      &c->seg_tok_off, &c->set_base, &c->set_mask, &c->seg_pairs, &c->desc, &c->gcache, &c->bucket_off, &c->rec_a, &c->nocc, &c->occoff, &c->occ_tok,
-                     &c->np_ab, &c->dot_off, &c->dots, &c->pool, &c->pool_cursor, &c->np_all, &c->pair_off, &c->seg_first_occ, &c->seg_tile_off,
+                     &c->occ_a, &c->exact_list, &c->exact_count, &c->np_ab, &c->dot_off, &c->dots, &c->pool, &c->pool_cursor, &c->np_all, &c->pair_off, &c->seg_first_occ, &c->seg_tile_off,
                      &c->seg_bucket_base, &c->seg_nbk_mask, &c->cursor, &c->giant_list, &c->giant_count, &c->tile_tab, &c->emb32, &c->inexact, &c->inex_list, &c->inex_count, &c->long_list, &c->long_count, &c->w2v_counts, &c->w2v_keep, &c->w2v_dropped, &c->w2v_aprob, &c->w2v_aidx, &c->w2v_syn0, &c->w2v_syn1, &c->ex_ids, &c->ex_starts, &c->ex_widths, &c->loss,
                      &c->occ, &c->hist, &c->stats, &c->flags};
     for (DevBuf* b : all) release(*b);

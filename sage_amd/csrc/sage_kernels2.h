@@ -147,25 +147,40 @@ __device__ __forceinline__ uint32_t window_pairs(uint32_t pl_, uint32_t c_, uint
 
 // ----------------------------------------------------------------------------------------------------------
 // k_describe: one thread per ablated occurrence walks it once.
-//   -> descriptor, ablated_sizes histogram, occurrences per id, position pairs per count segment, number of
-//      ablated-window pairs per occurrence (offsets of its dots), step statistics.
-//   LONG = false  every occurrence; a window that needs more than the 15 inline ids (or a base span the header cannot
-//                 hold) is abandoned and goes on the long list (one atomic per wave);
+//   -> descriptor, ablated id, ablated_sizes histogram, occurrences per id, position pairs per count segment and per
+//      occurrence (the distinct count's tiles), step statistics; with float32 row storage also the split of the
+//      occurrences into those whose window touches a row the float32 copy cannot hold (scored from the float64 matrix)
+//      and the rest (scored from the float32 copy): two lists, so that neither score kernel meets the other's work.
+//   LONG = false  every occurrence; a window that needs more than the 15 inline ids (or a base span above
+//                 SAGE_INLINE_MAX_M) is abandoned and goes on the long list;
 //   LONG = true   one thread per long-list entry: counting walk, pool allocation, second walk that writes the ids.
+// All list appends are aggregated per 256-thread tile: one global atomic per tile and list (a global atomic per wave on
+// one hot counter costs ~8 ns each and serialises).
 // ----------------------------------------------------------------------------------------------------------
+struct DescribeArgs {
+    uint4* desc;
+    uint32_t* occ_a;              // [n_occ] ablated id | (touches an inexact row) << 31
+    uint32_t* npairs_ab;          // [n_occ] position pairs of the ablated window (-> offsets of its dots)
+    uint32_t* npairs_all;         // [n_occ] ablated + base position pairs; 0 for a giant
+    uint32_t* giant_list; uint32_t* giant_count;
+    uint32_t* pool; uint32_t* pool_cursor; uint32_t pool_cap;
+    unsigned long long* seg_pairs;
+    unsigned long long* occ;
+    unsigned long long* hist; uint32_t hist_len;
+    unsigned long long* stats;
+    uint32_t* flags;
+    uint32_t* long_list; uint32_t* long_count;
+    const uint32_t* inexact;      // bitmap of the rows the float32 copy cannot hold; nullptr = one list-free score pass
+    uint32_t* exact_list; uint32_t* exact_count;
+    uint32_t* inex_list; uint32_t* inex_count;
+};
+#define SAGE_OCC_INEXACT 0x80000000u
+
 template <bool LONG>
 __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* __restrict__ occ_tok, uint32_t n_occ,
-                                                  SegPlan S, uint4* __restrict__ desc, uint32_t* __restrict__ npairs_ab,
-                                                  uint32_t* __restrict__ npairs_all /* ablated + base pairs; 0 for a giant */,
-                                                  uint32_t* __restrict__ giant_list, uint32_t* __restrict__ giant_count,
-                                                  uint32_t* __restrict__ pool, uint32_t* __restrict__ pool_cursor,
-                                                  uint32_t pool_cap, unsigned long long* __restrict__ seg_pairs,
-                                                  unsigned long long* __restrict__ occ,
-                                                  unsigned long long* __restrict__ hist, uint32_t hist_len,
-                                                  unsigned long long* __restrict__ stats, uint32_t* __restrict__ flags,
-                                                  uint32_t* __restrict__ long_list, uint32_t* __restrict__ long_count) {
+                                                  SegPlan S, DescribeArgs D) {
     __shared__ uint32_t rows[LONG ? 1 : 256 * DESC_LDS_STRIDE];
-    __shared__ uint32_t wcnt[5];
+    __shared__ uint32_t wcnt[3][5];
     __shared__ unsigned long long lseg[SEG_LDS];
     __shared__ uint32_t span[LONG ? 1 : DESC_SPAN];   // M[P0 .. P0 + DESC_SPAN).x of the tile: the walks read it from LDS
     __shared__ unsigned int lhist[32];
@@ -176,14 +191,15 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
     for (uint32_t i = threadIdx.x; i < DESC_ACC; i += 256) { occ_id[i] = ACC_EMPTY; occ_n[i] = 0; }
     __syncthreads();
     unsigned long long n_rows = 0, n_pairs = 0, n_wrows = 0, n_ab = 0;
-    const uint32_t n_items = LONG ? *long_count : n_occ;
+    const uint32_t n_items = LONG ? *D.long_count : n_occ;
     const uint32_t n_round = (n_items + 255u) & ~255u;
     uint32_t* my = rows + (LONG ? 0 : threadIdx.x * DESC_LDS_STRIDE);
-    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t* __restrict__ bitmap = D.inexact;
     for (uint32_t base = blockIdx.x * 256u; base < n_round; base += gridDim.x * 256u) {
         const uint32_t item = base + threadIdx.x;
         const bool live = item < n_items;
-        const uint32_t o = !live ? 0u : (LONG ? long_list[item] : item);
+        const uint32_t o = !live ? 0u : (LONG ? D.long_list[item] : item);
         uint32_t P0 = 0;
         if (!LONG) {
             // 256 consecutive occurrences cover ~1.5 KB of text; their walks stay within a few hundred bytes of it.
@@ -201,7 +217,7 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
         const uint32_t p0 = live ? A.occ_pos[o] : 0u;
         const uint32_t seg = live ? find_segment(S, t) : 0xFFFFFFFFu;
         unsigned long long my_pairs = 0;
-        bool is_long = false;
+        bool is_long = false, done = false, bad = false;
         if (live) {
             uint32_t L = 0;
             Ablation w;
@@ -219,28 +235,32 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
             if (is_long) {
                 my[0] = SAGE_DH_VALID | SAGE_DH_OVER;  // placeholder, rewritten by the long pass
             } else {
+                done = true;
                 uint32_t hdr = SAGE_DH_VALID | (w.never ? SAGE_DH_NEVER : 0u) | (w.pl << 24) | (w.pr << 26);
                 if (!LONG) {
                     my[0] = hdr | w.k | (w.m << 12);
+                    if (bitmap)      // independent loads of a 32 KB table, after the walk (not on its dependent chain)
+                        for (uint32_t j = 0; j < L; ++j) { const uint32_t id = my[1 + j]; bad = bad || ((bitmap[id >> 5] >> (id & 31u)) & 1u); }
                 } else {
-                    uint32_t at = atomicAdd(pool_cursor, L);
-                    const bool fits = at + L <= pool_cap && at + L >= at;
+                    uint32_t at = atomicAdd(D.pool_cursor, L);
+                    const bool fits = at + L <= D.pool_cap && at + L >= at;
                     // no room: the step is redone with a larger pool; until then the window points at the pool's first
                     // L ids (in bounds: pool_cap >= the longest possible window), so every reader stays in bounds
                     if (!fits) at = 0;
                     if (fits) {
                         uint32_t j = 0;          // second walk of a long window: ids straight into the pool
                         walk_occurrence(A, t, p0, ldx, [&](uint32_t id) {
-                            pool[at + j++] = id;
+                            D.pool[at + j++] = id;
+                            if (bitmap) bad = bad || ((bitmap[id >> 5] >> (id & 31u)) & 1u);
                             return true;
                         });
                     } else {
-                        flags[FLAG_POOL_FULL] = 1;
+                        D.flags[FLAG_POOL_FULL] = 1;
                     }
                     hdr |= SAGE_DH_OVER;
                     if ((unsigned long long)window_pairs(w.pl, w.k, w.pr) + window_pairs(w.pl, w.m, w.pr) > (unsigned long long)SAGE_PART_GIANT)
                         hdr |= SAGE_DH_GIANT;
-                    uint4* dst = desc + (size_t)o * 4;
+                    uint4* dst = D.desc + (size_t)o * 4;
                     dst[0] = make_uint4(hdr, at, w.k, w.m);
                     dst[1] = make_uint4(0, 0, 0, 0); dst[2] = make_uint4(0, 0, 0, 0); dst[3] = make_uint4(0, 0, 0, 0);
                 }
@@ -249,38 +269,49 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
                 n_rows += L + w.m;
                 n_wrows += L;
                 n_ab += ab_pairs;
-                npairs_ab[o] = ab_pairs;
+                D.occ_a[o] = w.a | (bad ? SAGE_OCC_INEXACT : 0u);
+                D.npairs_ab[o] = ab_pairs;
                 const bool giant = LONG && my_pairs > (unsigned long long)SAGE_PART_GIANT;
-                npairs_all[o] = giant ? 0u : (uint32_t)my_pairs;
-                if (giant) giant_list[atomicAdd(giant_count, 1u)] = o;      // rare: a line of thousands of tokens
-                acc_add_u32<DESC_ACC_BITS>(occ_id, occ_n, occ, w.a);
-                const uint32_t kk = w.k < hist_len ? w.k : hist_len - 1u;
-                if (kk < 32u) atomicAdd(&lhist[kk], 1u); else atomicAdd(&hist[kk], 1ull);
+                D.npairs_all[o] = giant ? 0u : (uint32_t)my_pairs;
+                if (giant) D.giant_list[atomicAdd(D.giant_count, 1u)] = o;      // rare: a line of thousands of tokens
+                acc_add_u32<DESC_ACC_BITS>(occ_id, occ_n, D.occ, w.a);
+                const uint32_t kk = w.k < D.hist_len ? w.k : D.hist_len - 1u;
+                if (kk < 32u) atomicAdd(&lhist[kk], 1u); else atomicAdd(&D.hist[kk], 1ull);
             }
         }
         n_pairs += my_pairs;
-        if (!LONG) {   // abandoned walks go on the long list: one global atomic per tile (hot counter)
-            const unsigned long long bal = __ballot(is_long);
-            const uint32_t wave = threadIdx.x >> 6;
-            if (lane == 0) wcnt[wave] = (uint32_t)__popcll(bal);
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                const uint32_t tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-                wcnt[4] = tot ? atomicAdd(long_count, tot) : 0u;
+        {   // list appends of the tile: abandoned walks -> long list; described occurrences -> exact / inexact lists
+            const bool f[3] = {is_long, done && bitmap != nullptr && !bad, done && bitmap != nullptr && bad};
+            uint32_t* const lists[3] = {D.long_list, D.exact_list, D.inex_list};
+            uint32_t* const counts[3] = {D.long_count, D.exact_count, D.inex_count};
+            unsigned long long bal[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                bal[q] = __ballot(f[q]);
+                if (lane == 0) wcnt[q][wave] = (uint32_t)__popcll(bal[q]);
             }
             __syncthreads();
-            if (is_long) {
-                uint32_t at = wcnt[4];
-                for (uint32_t w = 0; w < wave; ++w) at += wcnt[w];
-                long_list[at + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = o;
+            if (threadIdx.x < 3) {
+                const uint32_t q = threadIdx.x;
+                const uint32_t tot = wcnt[q][0] + wcnt[q][1] + wcnt[q][2] + wcnt[q][3];
+                const bool used = q == 0 ? !LONG : bitmap != nullptr;
+                wcnt[q][4] = (tot && used) ? atomicAdd(counts[q], tot) : 0u;
             }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                if (f[q] && (q != 0 || !LONG)) {
+                    uint32_t at = wcnt[q][4];
+                    for (uint32_t ww = 0; ww < wave; ++ww) at += wcnt[q][ww];
+                    lists[q][at + (uint32_t)__popcll(bal[q] & ((1ull << lane) - 1ull))] = o;
+                }
         }
         if (my_pairs) {   // pairs per segment: LDS for the first SEG_LDS segments of the batch, flushed once per workgroup
             if (seg < (uint32_t)SEG_LDS) atomicAdd(&lseg[seg], my_pairs);
-            else atomicAdd(&seg_pairs[seg], my_pairs);
+            else atomicAdd(&D.seg_pairs[seg], my_pairs);
         }
+        __syncthreads();
         if (!LONG) {
-            __syncthreads();
             // coalesced write-out of the block's 256 descriptors (4 x 16 B each)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -288,18 +319,18 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
                 const uint32_t row = q >> 2, col = (q & 3u) * 4u;
                 if (base + row < n_occ) {
                     const uint32_t* src = rows + row * DESC_LDS_STRIDE + col;
-                    desc[(size_t)(base + row) * 4 + (q & 3u)] = make_uint4(src[0], src[1], src[2], src[3]);
+                    D.desc[(size_t)(base + row) * 4 + (q & 3u)] = make_uint4(src[0], src[1], src[2], src[3]);
                 }
             }
             __syncthreads();
         }
     }
     __syncthreads();
-    if (threadIdx.x < 32 && threadIdx.x < hist_len && lhist[threadIdx.x])
-        atomicAdd(&hist[threadIdx.x], (unsigned long long)lhist[threadIdx.x]);
+    if (threadIdx.x < 32 && threadIdx.x < D.hist_len && lhist[threadIdx.x])
+        atomicAdd(&D.hist[threadIdx.x], (unsigned long long)lhist[threadIdx.x]);
     for (uint32_t i = threadIdx.x; i < DESC_ACC; i += 256)
-        if (occ_n[i]) atomicAdd(&occ[occ_id[i]], (unsigned long long)occ_n[i]);
-    if (threadIdx.x < SEG_LDS && threadIdx.x < S.n_seg && lseg[threadIdx.x]) atomicAdd(&seg_pairs[threadIdx.x], lseg[threadIdx.x]);
+        if (occ_n[i]) atomicAdd(&D.occ[occ_id[i]], (unsigned long long)occ_n[i]);
+    if (threadIdx.x < SEG_LDS && threadIdx.x < S.n_seg && lseg[threadIdx.x]) atomicAdd(&D.seg_pairs[threadIdx.x], lseg[threadIdx.x]);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         n_rows += __shfl_down(n_rows, d, 64);
@@ -308,12 +339,12 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
         n_ab += __shfl_down(n_ab, d, 64);
     }
     if (lane == 0) {
-        if (n_rows) atomicAdd(&stats[STAT_ROWS], n_rows);
-        if (n_pairs) atomicAdd(&stats[STAT_PAIRS], n_pairs);
-        if (n_wrows) atomicAdd(&stats[STAT_WROWS], n_wrows);
-        if (n_ab) atomicAdd(&stats[STAT_ABPAIRS], n_ab);
+        if (n_rows) atomicAdd(&D.stats[STAT_ROWS], n_rows);
+        if (n_pairs) atomicAdd(&D.stats[STAT_PAIRS], n_pairs);
+        if (n_wrows) atomicAdd(&D.stats[STAT_WROWS], n_wrows);
+        if (n_ab) atomicAdd(&D.stats[STAT_ABPAIRS], n_ab);
     }
-    if (LONG && blockIdx.x == 0 && threadIdx.x == 0 && n_items) atomicAdd(&stats[STAT_LONG], (unsigned long long)n_items);
+    if (LONG && blockIdx.x == 0 && threadIdx.x == 0 && n_items) atomicAdd(&D.stats[STAT_LONG], (unsigned long long)n_items);
 }
 
 // Row slice of one lane: EPL doubles as EPL/2 16-byte loads; the G lanes of a group cover one 128-byte line per
@@ -580,19 +611,18 @@ __global__ __launch_bounds__(256) void k_dots(const uint4* __restrict__ desc, co
 #define LOGSIG_PF 8      // dots of a thread's slice loaded ahead (a tile of 256 occurrences has ~8 dots per thread)
 #define LOGSIG_WIN 6     // pair-cache entries t-2 .. t+3 loaded ahead (centres of up to 4 base tokens)
 __global__ __launch_bounds__(256) void k_logsig(const uint4* __restrict__ desc, const uint32_t* __restrict__ occ_tok,
-                                                const uint32_t* __restrict__ tok_w0, uint32_t n_occ,
+                                                const uint32_t* __restrict__ occ_a, uint32_t n_occ,
                                                 const uint32_t* __restrict__ dot_off, const double* __restrict__ dots,
                                                 const double2* __restrict__ Gc, double* __restrict__ loss,
-                                                uint32_t* __restrict__ fix_list, uint32_t* __restrict__ fix_count) {
-    // fix_list != nullptr (float32 row storage): rows that float32 cannot hold are stored as NaN, so an occurrence
-    // whose sum comes out NaN touched one; it is not accumulated but listed for the float64 pass (k_dots on the list,
-    // then k_logsig_list).
+                                                const uint32_t* __restrict__ inex_count, unsigned long long* __restrict__ stats) {
+    // Every dot is in place when this runs: with float32 row storage k_describe has split the occurrences, the ones
+    // whose rows the float32 copy holds exactly got their dots from it, the others from the float64 matrix.  A NaN dot
+    // is therefore the caller's own NaN (or inf * 0) and goes into the loss as the reference's would.
+    if (inex_count && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[STAT_INEXACT], (unsigned long long)*inex_count);
     __shared__ uint32_t acc_id[ACC_SLOTS];
     __shared__ double acc_val[ACC_SLOTS];
     __shared__ uint32_t off[LOGSIG_TILE + 1];
     __shared__ double osum[LOGSIG_TILE];
-    __shared__ uint32_t wcnt[5];
-    __shared__ uint32_t obad[LOGSIG_TILE];   // the occurrence has a NaN dot (a row the float32 copy cannot hold)
     for (uint32_t i = threadIdx.x; i < ACC_SLOTS; i += 256) { acc_id[i] = ACC_EMPTY; acc_val[i] = 0.0; }
     const double* Gd = reinterpret_cast<const double*>(Gc);
     for (uint32_t o0 = blockIdx.x * LOGSIG_TILE; o0 < n_occ; o0 += gridDim.x * LOGSIG_TILE) {
@@ -601,7 +631,6 @@ __global__ __launch_bounds__(256) void k_logsig(const uint4* __restrict__ desc, 
         if (threadIdx.x < nt) off[threadIdx.x] = dot_off[o0 + threadIdx.x];
         if (threadIdx.x == 0) off[nt] = dot_off[o0 + nt];   // nt can be 256: there is no thread 256
         osum[threadIdx.x] = 0.0;
-        obad[threadIdx.x] = 0u;
         // phase-2 operands are independent of phase 1: issue their loads first
         const uint32_t o = o0 + threadIdx.x;
         uint4 h = make_uint4(0, 0, 0, 0);
@@ -622,7 +651,7 @@ __global__ __launch_bounds__(256) void k_logsig(const uint4* __restrict__ desc, 
         double2 W[LOGSIG_WIN];
         uint32_t a_w0 = 0;
         if (live) {
-            a_w0 = tok_w0[t];
+            a_w0 = occ_a[o];
             if (small) {
 #pragma unroll
                 for (int q = 0; q < LOGSIG_WIN; ++q) {
@@ -664,16 +693,13 @@ __global__ __launch_bounds__(256) void k_logsig(const uint4* __restrict__ desc, 
             }
             uint32_t own = lo, nxt = off[own + 1];
             double acc = 0.0;
-            bool bad = false;
             uint32_t q = 0;
             for (; i < iend; ++i, ++q) {
                 if (i >= nxt) {
                     unsafeAtomicAdd(&osum[own], acc);
-                    if (bad) obad[own] = 1u;
-                    acc = 0.0; bad = false;
+                    acc = 0.0;
                     do { ++own; nxt = off[own + 1]; } while (i >= nxt);
                 }
-                // NaN never enters exp/log1p (their special-case paths are slow and a wave takes them for one lane)
                 double x;
                 if (q < LOGSIG_PF) {
                     x = v[0];
@@ -682,88 +708,15 @@ __global__ __launch_bounds__(256) void k_logsig(const uint4* __restrict__ desc, 
                 } else {
                     x = dots[i];
                 }
-                const bool isn = x != x;
-                bad = bad || isn;
-                acc += log_sigmoid(isn ? 0.0 : x);
+                acc += log_sigmoid(x);
             }
             unsafeAtomicAdd(&osum[own], acc);
-            if (bad) obad[own] = 1u;
         }
         __syncthreads();
-        bool redo = false;
-        if (live) {
-            const uint32_t a = SAGE_T_ID(a_w0);
-            const double sum = osum[threadIdx.x];
-            redo = fix_list != nullptr && obad[threadIdx.x] != 0u;
-            // without a fix list a NaN dot is the caller's own NaN: it goes into the loss as the reference's would
-            const double nan_in = (fix_list == nullptr && obad[threadIdx.x] != 0u) ? __builtin_nan("") : 0.0;
-            if (!redo) acc_add_f64(acc_id, acc_val, loss, a, -2.0 * (sum - sb) + nan_in);
-        }
-        if (fix_list) {   // one global atomic per tile: rank inside the wave, wave offsets through LDS
-            const unsigned long long bal = __ballot(redo);
-            const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-            if (lane == 0) wcnt[wave] = (uint32_t)__popcll(bal);
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                const uint32_t tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-                wcnt[4] = tot ? atomicAdd(fix_count, tot) : 0u;
-            }
-            __syncthreads();
-            if (redo) {
-                uint32_t at = wcnt[4];
-                for (uint32_t w = 0; w < wave; ++w) at += wcnt[w];
-                fix_list[at + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = o;
-            }
-        }
+        if (live) acc_add_f64(acc_id, acc_val, loss, SAGE_T_ID(a_w0), -2.0 * (osum[threadIdx.x] - sb));
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < ACC_SLOTS; i += 256)
         if (acc_id[i] != ACC_EMPTY) unsafeAtomicAdd(&loss[acc_id[i]], acc_val[i]);
 }
 
-// The same for the occurrences on a list (their dots recomputed from the float64 matrix): 8 lanes per occurrence.
-__global__ __launch_bounds__(256) void k_logsig_list(const uint4* __restrict__ desc, const uint32_t* __restrict__ occ_tok,
-                                                     const uint32_t* __restrict__ tok_w0,
-                                                     const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count,
-                                                     const uint32_t* __restrict__ dot_off, const double* __restrict__ dots,
-                                                     const double2* __restrict__ Gc, double* __restrict__ loss,
-                                                     unsigned long long* __restrict__ stats) {
-    constexpr int G = 8;
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[STAT_INEXACT], (unsigned long long)*list_count);
-    __shared__ uint32_t acc_id[ACC_SLOTS];
-    __shared__ double acc_val[ACC_SLOTS];
-    for (uint32_t i = threadIdx.x; i < ACC_SLOTS; i += 256) { acc_id[i] = ACC_EMPTY; acc_val[i] = 0.0; }
-    __syncthreads();
-    const uint32_t n = *list_count;
-    const uint32_t gl = threadIdx.x % G;
-    const double* Gd = reinterpret_cast<const double*>(Gc);
-    const uint32_t n_round = (n + 31u) & ~31u;
-    for (uint32_t e0 = blockIdx.x * 32u; e0 < n_round; e0 += gridDim.x * 32u) {
-        const uint32_t e = e0 + threadIdx.x / G;
-        double acc = 0.0;
-        uint32_t a = 0;
-        if (e < n) {
-            const uint32_t o = list[e];
-            const uint4 h = desc[(size_t)o * 4];
-            const Win w = win_decode(h.x, h.z, h.w);
-            const uint32_t t = occ_tok[o];
-            a = SAGE_T_ID(tok_w0[t]);
-            const uint32_t d0 = dot_off[o], d1 = dot_off[o + 1];
-            for (uint32_t i = d0 + gl; i < d1; i += G) acc += log_sigmoid(dots[i]);
-            const int im = (int)w.m, ipl = (int)w.pl, ipr = (int)w.pr;
-            const int lo1 = ipl >= 1 ? -1 : 0, hi1 = im - 2 + (ipr >= 1 ? 1 : 0);
-            const int lo2 = -ipl, hi2 = im + ipr - 3;
-            double sb = 0.0;
-            for (int rel = lo1 + (int)gl; rel <= hi1; rel += G) sb += Gd[((size_t)t + rel) * 2];
-            for (int rel = lo2 + (int)gl; rel <= hi2; rel += G)
-                if ((rel >= 0 && rel <= im - 1) || (rel + 2 >= 0 && rel + 2 <= im - 1)) sb += Gd[((size_t)t + rel) * 2 + 1];
-            acc -= sb;
-        }
-#pragma unroll
-        for (int mm = G / 2; mm >= 1; mm >>= 1) acc += __shfl_xor(acc, mm, G);
-        if (gl == 0 && e < n) acc_add_f64(acc_id, acc_val, loss, a, -2.0 * acc);
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < ACC_SLOTS; i += 256)
-        if (acc_id[i] != ACC_EMPTY) unsafeAtomicAdd(&loss[acc_id[i]], acc_val[i]);
-}
