@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
 """Summarise gpurun_out/prof (written by profiles/collect.sh) into profiles/<tag>_*: the rocprofv3 kernel stats
 CSV as is, the bench JSON lines, and a per-kernel table of FETCH_SIZE / WRITE_SIZE (KiB as rocprofv3 reports them,
-summed over XCDs, per launch).  FETCH_SIZE on gfx950 counts 64 B per 128-B request for 16-B-per-lane streaming reads
-(MI355X_MICROARCH.md, HBM section), so `fetch_x2` is the figure to compare with byte counts for such kernels."""
+summed over XCDs, per launch).  FETCH_SIZE on gfx950 counts 64 B per 128-B request (MI355X_MICROARCH.md, HBM section);
+profiles/r02_pmc_calibration.json (tools/calib_pmc) measured the same factor 2.00 for this library's read shapes --
+16-B-per-lane streams AND the 8-lane x 16-B row gathers of k_dots / k_pair_cache -- so `fetch_x2` is the read figure
+for every kernel here.  WRITE_SIZE is exact for 16-B-per-lane streams, 64-byte chunks and runs of 8-byte records, and
+4x the bytes for isolated 8-byte stores (32-byte granules); `calibrated` = fetch_x2 + write, the figure bench.py
+quotes as `traffic`."""
 import collections
 import csv
 import json
@@ -30,7 +34,8 @@ for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["FETCH_SIZE"]):
     n = max(1, a["launches"])
     rows.append({"kernel": k, "launches": a["launches"], "fetch_GB_per_launch": a["FETCH_SIZE"] * 1024 / n / 1e9,
                  "fetch_x2_GB_per_launch": 2 * a["FETCH_SIZE"] * 1024 / n / 1e9,
-                 "write_GB_per_launch": a["WRITE_SIZE"] * 1024 / n / 1e9})
+                 "write_GB_per_launch": a["WRITE_SIZE"] * 1024 / n / 1e9,
+                 "calibrated_GB_per_launch": (2 * a["FETCH_SIZE"] + a["WRITE_SIZE"]) * 1024 / n / 1e9})
 # Whole-step HBM-side bytes: per-launch bytes x launches per timed step.  The kernel-trace run holds 4 steps (1 warm-up
 # + 3 timed) plus the set-up tokenization, the PMC runs hold 1 step plus the same set-up, so the difference / 3 is the
 # number of launches one step makes.
@@ -44,7 +49,7 @@ for r in rows:
     step_fetch += r["fetch_x2_GB_per_launch"] * per_step
     step_write += r["write_GB_per_launch"] * per_step
 rows.append({"kernel": "__step_total__", "launches": 0, "fetch_GB_per_launch": step_fetch / 2, "fetch_x2_GB_per_launch": step_fetch,
-             "write_GB_per_launch": step_write, "launches_per_step": 1.0})
+             "write_GB_per_launch": step_write, "calibrated_GB_per_launch": step_fetch + step_write, "launches_per_step": 1.0})
 json.dump(rows, open(dst / f"{tag}_pmc_traffic.json", "w"), indent=1)
 print(f"step total: fetch x2 {step_fetch:.1f} GB + write {step_write:.1f} GB")
 for r in rows[:12]:

@@ -181,9 +181,16 @@ __device__ __forceinline__ bool probe_exact(const VocabDev& v, uint32_t b, uint3
     }
 }
 
-// The two longest matches found so far, longest first (hits = how many are filled in).
+// The two longest matches found so far as packed words id | len << 20 (the match table's own format), m1 >= m2, 0 = none.
+// A match of any length folds in with two instructions, whatever order the lengths come in: the word's high bits are
+// the length, so the largest word is the longest match and the median of (m1, m2, new) the second longest.
 struct Top2 {
-    uint32_t id1, len1, id2, len2, hits;
+    uint32_t m1, m2;
+    __device__ __forceinline__ void fold(uint32_t r) {      // r = id | len << 20, or 0 for "no match at this length"
+        const uint32_t second = max(m2, min(m1, r));     // the median of the three, given m1 >= m2
+        m1 = max(m1, r);
+        m2 = second;
+    }
 };
 
 // Probes the candidate lengths JLO..JHI (at most 8) with all loads of a phase in flight together.  Branch-free:
@@ -246,13 +253,7 @@ __device__ __forceinline__ void probe_chunk(const VocabDev& v, uint32_t cand, co
             }
     }
 #pragma unroll
-    for (int i = N - 1; i >= 0; --i) {
-        const bool take = ((hitm >> i) & 1u) && top.hits < 2u;
-        const bool first = take && top.hits == 0u, second = take && top.hits == 1u;
-        top.id1 = first ? cid[i] : top.id1;  top.len1 = first ? (uint32_t)(JLO + i) : top.len1;
-        top.id2 = second ? cid[i] : top.id2; top.len2 = second ? (uint32_t)(JLO + i) : top.len2;
-        top.hits += take ? 1u : 0u;
-    }
+    for (int i = N - 1; i >= 0; --i) top.fold(((hitm >> i) & 1u) ? (cid[i] | ((uint32_t)(JLO + i) << 20)) : 0u);
 }
 
 // Lengths above 8 are sparse once the prefix tables have spoken (a few lanes of a wave have a candidate there, and
@@ -278,14 +279,14 @@ __device__ __forceinline__ void probe_sparse(const VocabDev& v, uint32_t cand, c
     constexpr int N = JHI - JLO + 1;
     constexpr int PW = 2;   // candidates a lane probes per round: both bucket loads, then both key loads, in flight together
     uint32_t c = (cand >> (JLO - 1)) & ((N >= 32) ? 0xFFFFFFFFu : ((1u << N) - 1u));   // bit i <-> length JLO + i
-    while (__any(c != 0u && top.hits < 2u)) {
+    while (__any(c != 0u && top.m2 == 0u)) {
         bool active[PW], have[PW];
         uint32_t j[PW], w[PW], b[PW], id[PW];
         uint4 bk[PW];
         uint64_t K[PW][NW];
 #pragma unroll
         for (int r = 0; r < PW; ++r) {
-            active[r] = c != 0u && top.hits < 2u;
+            active[r] = c != 0u && top.m2 == 0u;
             const uint32_t i = active[r] ? 31u - (uint32_t)__clz((int)c) : 0u;
             c = active[r] ? (c & ~(1u << i)) : c;
             j[r] = (uint32_t)JLO + i;
@@ -326,11 +327,7 @@ __device__ __forceinline__ void probe_sparse(const VocabDev& v, uint32_t cand, c
             // rare: a tag match that fails the key compare, or a full bucket without a match -> exact serial probe
             if (active[r] && !eq && (have[r] || bk[r].w != SAGE_SLOT_EMPTY))
                 eq = probe_exact<NW>(v, b[r], w[r] >> 20, W, (int)j[r], id[r]);
-            const bool take = active[r] && eq && top.hits < 2u;
-            const bool first = take && top.hits == 0u, second = take && top.hits == 1u;
-            top.id1 = first ? id[r] : top.id1;  top.len1 = first ? j[r] : top.len1;
-            top.id2 = second ? id[r] : top.id2; top.len2 = second ? j[r] : top.len2;
-            top.hits += take ? 1u : 0u;
+            top.fold((active[r] && eq) ? (id[r] | (j[r] << 20)) : 0u);
         }
     }
 }
@@ -409,29 +406,25 @@ __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ 
         uint64_t W[NW];
 #pragma unroll
         for (int w = 0; w < NW; ++w) W[w] = (uint64_t)T[2 * w] | ((uint64_t)T[2 * w + 1] << 32);
-        Top2 top{0, 0, 0, 0, 0};
+        Top2 top{0u, 0u};
         // chunks from the longest lengths down.  A chunk runs if ANY lane of the wave still needs it (wave-uniform
         // branch); lanes that do not take part are masked through their candidate bits, not through EXEC.
         if constexpr (NW >= 2) probe_sparse<NW, 9, ML, ML>(v, cand, fh, W, top);
         {
-            const uint32_t c1 = top.hits < 2u ? cand : 0u;
+            const uint32_t c1 = top.m2 == 0u ? cand : 0u;
             if (__any((c1 & 0xF0u) != 0u)) probe_chunk<NW, 5, 8, ML>(v, c1, fh, W, top);
-            const uint32_t c2 = top.hits < 2u ? cand : 0u;
+            const uint32_t c2 = top.m2 == 0u ? cand : 0u;
             if (__any((c2 & 0x0Cu) != 0u)) probe_chunk<NW, 3, 4, ML>(v, c2, fh, W, top);
         }
         // 2-byte keys need no hash: a 256 KiB table indexed by the two bytes (load issued at the top of the tile)
-        if (top.hits < 2u && lim >= 2u && d2 != SAGE_SLOT_EMPTY) {
-            if (top.hits == 0u) { top.id1 = d2; top.len1 = 2; } else { top.id2 = d2; top.len2 = 2; }
-            ++top.hits;
-        }
+        top.fold((lim >= 2u && d2 != SAGE_SLOT_EMPTY) ? (d2 | (2u << 20)) : 0u);
         // the single byte always matches: it is the longest match when nothing else hit, the second when one did
-        const uint32_t idb = v.byte_id[T[0] & 0xFFu];
-        if (top.hits == 0u) { top.id1 = idb; top.len1 = 1; }
-        else if (top.hits == 1u) { top.id2 = idb; top.len2 = 1; }
+        top.fold(v.byte_id[T[0] & 0xFFu] | (1u << 20));
+        // (more than two matches may have been folded in -- a chunk probes all its lengths -- m1 and m2 are the two
+        // longest of them in any case; with a single match m2 is 0 = "no second match", len2 == 0 iff len1 == 1)
         // streamed once: keep it out of the way of the table and key planes in L2
-        const uint32_t ends1 = top.len1 == rm ? 0x80000000u : 0u;
-        __builtin_nontemporal_store((uint64_t)(top.id1 | (top.len1 << 20) | ends1) | ((uint64_t)(top.id2 | (top.len2 << 20)) << 32),
-                                    reinterpret_cast<uint64_t*>(M + rel));
+        const uint32_t ends1 = SAGE_M_LEN(top.m1) == rm ? 0x80000000u : 0u;
+        __builtin_nontemporal_store((uint64_t)(top.m1 | ends1) | ((uint64_t)top.m2 << 32), reinterpret_cast<uint64_t*>(M + rel));
     }
 }
 
