@@ -157,6 +157,14 @@ int sage_set_count_mode(sage_ctx* ctx, int mode);
  * switch: it forces the mixed path).  Takes effect at the next sage_set_embeddings, which must follow. */
 int sage_set_score_mode(sage_ctx* ctx, int mode);
 
+/* Reproducible float sums (no counterpart in the reference, whose own merge order is the workers' completion order,
+ * utils.py:159-183).  By default the per-occurrence loss terms are added with float64 atomics: integers are exact, the
+ * losses of two runs agree to ~1e-12 relative.  With enabled != 0 every log-sigmoid term is converted to 128-bit fixed
+ * point (units of 2^-60) before anything is added and all sums are integer sums: out_loss is then bit-identical from run
+ * to run and for any batch size (sage_set_batch_bytes), at ~1 ms per step on the 1M-line workload.  It differs from the
+ * default by the truncation of each term to 2^-60 (<< 1e-5 relative on the per-token loss). */
+int sage_set_deterministic(sage_ctx* ctx, int enabled);
+
 /* word2vec retraining on the GPU.  Replaces the host call
  *   gensim.models.Word2Vec(corpus_file=..., vector_size=D, negative=N, alpha=ALPHA, window=window_size,
  *                          min_count=min_count, sg=1, workers=workers)        (embeddings.py:68-75)

@@ -73,6 +73,8 @@ def load():
     lib.sage_set_score_mode.argtypes = [vp, C.c_int]
     lib.sage_set_count_mode.restype = C.c_int
     lib.sage_set_count_mode.argtypes = [vp, C.c_int]
+    lib.sage_set_deterministic.restype = C.c_int
+    lib.sage_set_deterministic.argtypes = [vp, C.c_int]
     lib.sage_train_embeddings.restype = C.c_int
     lib.sage_train_embeddings.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32, C.c_double,
                                           C.c_int32, C.c_uint64, C.c_int64, C.POINTER(C.c_double), pi64]
@@ -85,7 +87,7 @@ def load():
 EXPORTED = ["sage_version", "sage_create", "sage_destroy", "sage_last_error", "sage_set_vocab", "sage_set_corpus",
             "sage_set_embeddings", "sage_tokenize", "sage_tokenize_noalloc", "sage_ablation_step", "sage_ablation_step_device",
             "sage_set_profiling", "sage_reset_kernel_times", "sage_get_kernel_times", "sage_set_batch_bytes",
-            "sage_set_match_mode", "sage_set_count_mode", "sage_set_score_mode", "sage_train_embeddings", "sage_get_step_stats"]
+            "sage_set_match_mode", "sage_set_count_mode", "sage_set_score_mode", "sage_set_deterministic", "sage_train_embeddings", "sage_get_step_stats"]
 
 
 class HipSage:
@@ -245,6 +247,10 @@ class HipSage:
         """0 = float32 row storage where lossless (default), 1 = float64 storage; call before set_embeddings."""
         self._check(self._lib.sage_set_score_mode(self._h, int(mode)))
         self.cache.pop("emb", None)     # the library drops its matrix: the next step must upload it again
+
+    def set_deterministic(self, on: bool):
+        """Fixed-point loss sums: bit-identical losses from run to run and for any batch size (sage_set_deterministic)."""
+        self._check(self._lib.sage_set_deterministic(self._h, 1 if on else 0))
 
     def train_embeddings(self, vsize: int, dim: int, window: int = 5, negative: int = 15, alpha: float = 0.025,
                          min_alpha: float = 1e-4, epochs: int = 5, sample: float = 1e-3, min_count: int = 1, seed: int = 1):

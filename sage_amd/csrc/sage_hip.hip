@@ -98,6 +98,8 @@ struct sage_ctx {
     bool count_fallback = false;   // an LDS set overflowed: v1 until the vocabulary or the corpus changes
     DevBuf ex_ids, ex_starts, ex_widths;
     DevBuf loss, occ, hist, stats, flags;
+    DevBuf loss_fix;              // deterministic mode: 128-bit fixed-point loss sums, two words per id
+    bool deterministic = false;
     int64_t batch_bytes = 256ll << 20;
     int set_factor = 16;
 
@@ -242,12 +244,16 @@ void launch_match_and_count(sage_ctx* c, const MatchBufs& B, int64_t line0, uint
         const int nw = (c->max_len + 7) / 8;
         if (c->match_mode == 0) {
             const uint32_t pgrid = std::min<uint32_t>(cdiv(nb, 1024), (uint32_t)c->n_cu);
-            switch (nw) {
-            case 1: k_match_lds<1><<<pgrid, 1024, 0, c->stream>>>(B.corpus, B.rem, pos0, (uint32_t)nb, v, B.M); break;
-            case 2: k_match_lds<2><<<pgrid, 1024, 0, c->stream>>>(B.corpus, B.rem, pos0, (uint32_t)nb, v, B.M); break;
-            case 3: k_match_lds<3><<<pgrid, 1024, 0, c->stream>>>(B.corpus, B.rem, pos0, (uint32_t)nb, v, B.M); break;
-            default: k_match_lds<4><<<pgrid, 1024, 0, c->stream>>>(B.corpus, B.rem, pos0, (uint32_t)nb, v, B.M); break;
-            }
+#define SAGE_MATCH_LDS(NW_, ML_) k_match_lds<NW_, ML_><<<pgrid, 1024, 0, c->stream>>>(B.corpus, B.rem, pos0, (uint32_t)nb, v, B.M)
+            const int ml = c->max_len;      // the smallest instantiation that covers max_len
+            if (ml <= 8) SAGE_MATCH_LDS(1, 8);
+            else if (ml <= 12) SAGE_MATCH_LDS(2, 12);
+            else if (ml <= 16) SAGE_MATCH_LDS(2, 16);
+            else if (ml <= 17) SAGE_MATCH_LDS(3, 17);
+            else if (ml <= 20) SAGE_MATCH_LDS(3, 20);
+            else if (ml <= 24) SAGE_MATCH_LDS(3, 24);
+            else SAGE_MATCH_LDS(4, 32);
+#undef SAGE_MATCH_LDS
         } else switch (nw) {
         case 1: k_match<1><<<grid, 256, 0, c->stream>>>(B.corpus, B.rem, pos0, (uint32_t)nb, v, B.M); break;
         case 2: k_match<2><<<grid, 256, 0, c->stream>>>(B.corpus, B.rem, pos0, (uint32_t)nb, v, B.M); break;
@@ -384,10 +390,18 @@ void launch_score(sage_ctx* c, const uint32_t* tok_w0, uint32_t n_tok, uint32_t 
     {
         Prof p(c, SAGE_K_LOGSIG);
         const uint32_t grid = std::min<uint32_t>(cdiv(n_occ, LOGSIG_TILE), 256u * 8u);
-        k_logsig<<<grid, 256, 0, c->stream>>>(c->desc.as<uint4>(), c->occ_tok.as<uint32_t>(), c->occ_a.as<uint32_t>(), n_occ,
-                                              c->dot_off.as<uint32_t>(), c->dots.as<double>(), c->gcache.as<double2>(),
-                                              c->loss.as<double>(), split ? c->inex_count.as<uint32_t>() : nullptr,
-                                              c->stats.as<unsigned long long>());
+        if (c->deterministic)
+            k_logsig<true><<<grid, 256, 0, c->stream>>>(c->desc.as<uint4>(), c->occ_tok.as<uint32_t>(), c->occ_a.as<uint32_t>(), n_occ,
+                                                        c->dot_off.as<uint32_t>(), c->dots.as<double>(), c->gcache.as<double2>(),
+                                                        c->loss.as<double>(), c->loss_fix.as<unsigned long long>(),
+                                                        split ? c->inex_count.as<uint32_t>() : nullptr,
+                                                        c->stats.as<unsigned long long>());
+        else
+            k_logsig<false><<<grid, 256, 0, c->stream>>>(c->desc.as<uint4>(), c->occ_tok.as<uint32_t>(), c->occ_a.as<uint32_t>(), n_occ,
+                                                         c->dot_off.as<uint32_t>(), c->dots.as<double>(), c->gcache.as<double2>(),
+                                                         c->loss.as<double>(), nullptr,
+                                                         split ? c->inex_count.as<uint32_t>() : nullptr,
+                                                         c->stats.as<unsigned long long>());
     }
 }
 
@@ -408,9 +422,11 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
     if ((rc = ensure(c, c->hist, (size_t)hist_len * 8))) return rc;
     if ((rc = ensure(c, c->stats, STAT_COUNT * 8))) return rc;
     if ((rc = ensure(c, c->pool_cursor, 4))) return rc;
+    if (c->deterministic && (rc = ensure(c, c->loss_fix, (size_t)vsize * 16))) return rc;
 
     for (int attempt = 0;; ++attempt) {
         HIP_TRY(c, hipMemsetAsync(c->loss.p, 0, (size_t)vsize * 8, c->stream));
+        if (c->deterministic) HIP_TRY(c, hipMemsetAsync(c->loss_fix.p, 0, (size_t)vsize * 16, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->occ.p, 0, (size_t)vsize * 8, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->hist.p, 0, (size_t)hist_len * 8, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->stats.p, 0, STAT_COUNT * 8, c->stream));
@@ -653,6 +669,9 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
             HIP_TRY(c, hipGetLastError());
             sa = sb;
         }
+        if (c->deterministic)
+            k_fix_finish<<<cdiv((uint64_t)vsize, 256), 256, 0, c->stream>>>(c->loss_fix.as<unsigned long long>(), (uint32_t)vsize,
+                                                                           c->loss.as<double>());
         uint32_t flags[FLAG_COUNT];
         uint64_t stats[STAT_COUNT];
         HIP_TRY(c, hipMemcpyAsync(flags, c->flags.p, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
@@ -741,7 +760,7 @@ void sage_destroy(sage_ctx* c) {
                      &c->seg_tok_off, &c->set_base, &c->set_mask, &c->seg_pairs, &c->desc, &c->gcache, &c->bucket_off, &c->rec_a, &c->nocc, &c->occoff, &c->occ_tok,
                      &c->occ_a, &c->exact_list, &c->exact_count, &c->np_ab, &c->dot_off, &c->dots, &c->pool, &c->pool_cursor, &c->np_all, &c->pair_off, &c->seg_first_occ, &c->seg_tile_off,
                      &c->seg_bucket_base, &c->seg_nbk_mask, &c->cursor, &c->giant_list, &c->giant_count, &c->tile_tab, &c->emb32, &c->inexact, &c->inex_list, &c->inex_count, &c->long_list, &c->long_count, &c->w2v_counts, &c->w2v_keep, &c->w2v_dropped, &c->w2v_aprob, &c->w2v_aidx, &c->w2v_syn0, &c->w2v_syn1, &c->ex_ids, &c->ex_starts, &c->ex_widths, &c->loss,
-                     &c->occ, &c->hist, &c->stats, &c->flags};
+                     &c->occ, &c->hist, &c->stats, &c->flags, &c->loss_fix};
     for (DevBuf* b : all) release(*b);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -868,8 +887,8 @@ int sage_set_corpus(sage_ctx* c, const uint8_t* bytes, const int64_t* line_offse
     c->n_lines = n_lines;
     c->nbytes = nbytes;
     if (nbytes) {
-        k_line_remaining<<<cdiv(nbytes, 256), 256, 0, c->stream>>>(c->line_off.as<int64_t>(), n_lines,
-                                                                   c->rem.as<uint8_t>(), nbytes);
+        k_line_remaining<<<(uint32_t)std::min<uint64_t>(((uint64_t)nbytes + 255) / 256, 1u << 20), 256, 0, c->stream>>>(
+            c->line_off.as<int64_t>(), n_lines, c->rem.as<uint8_t>(), nbytes);
         HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
@@ -1168,7 +1187,7 @@ int sage_tokenize_noalloc(sage_ctx* c, const uint8_t* d_text, int64_t n_bytes, c
     HIP_TRY(c, hipMemsetAsync(S + NA_TOTAL, 0, 16, c->stream));
     HIP_TRY(c, hipMemsetAsync(S + NA_FLAGS, 0, FLAG_COUNT * 4, c->stream));
     if (n_bytes)
-        k_line_remaining<<<cdiv((uint64_t)n_bytes, 256), 256, 0, c->stream>>>(d_line_offsets, n_lines, rem, n_bytes);
+        k_line_remaining<<<cdiv((uint64_t)n_bytes, 256), 256, 0, c->stream>>>(d_line_offsets, n_lines, rem, n_bytes);   // <= 1 MiB
     launch_match_and_count(c, B, 0, nl, 0, (uint64_t)n_bytes);
     HIP_TRY(c, hipGetLastError());
     uint64_t total = 0;
@@ -1257,6 +1276,12 @@ int sage_set_score_mode(sage_ctx* c, int mode) {
 int sage_set_count_mode(sage_ctx* c, int mode) {
     if (!c || (mode != 0 && mode != 1)) return fail(c, SAGE_E_ARG, "count mode must be 0 or 1");
     c->count_mode = mode;
+    return SAGE_OK;
+}
+
+int sage_set_deterministic(sage_ctx* c, int enabled) {
+    if (!c) return SAGE_E_ARG;
+    c->deterministic = enabled != 0;
     return SAGE_OK;
 }
 

@@ -31,16 +31,17 @@ enum { STAT_OCC = 0, STAT_ROWS = 1, STAT_PAIRS = 2, STAT_DISTINCT = 3, STAT_INEX
 // ----------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_line_remaining(const int64_t* __restrict__ line_off, int64_t n_lines,
                                                         uint8_t* __restrict__ rem, int64_t nbytes) {
-    int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= nbytes) return;
-    // upper_bound(line_off, p) over line_off[1..n_lines]; lanes of a wave walk nearly the same path (L1 hits)
-    int64_t lo = 0, hi = n_lines;  // find smallest l with line_off[l+1] > p
-    while (lo < hi) {
-        int64_t mid = (lo + hi) >> 1;
-        if (line_off[mid + 1] > p) hi = mid; else lo = mid + 1;
+    // grid-stride: a launch may not have 2^32 threads or more, and a corpus may have more bytes than that
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < nbytes; p += (int64_t)gridDim.x * 256) {
+        // upper_bound(line_off, p) over line_off[1..n_lines]; lanes of a wave walk nearly the same path (L1 hits)
+        int64_t lo = 0, hi = n_lines;  // find smallest l with line_off[l+1] > p
+        while (lo < hi) {
+            int64_t mid = (lo + hi) >> 1;
+            if (line_off[mid + 1] > p) hi = mid; else lo = mid + 1;
+        }
+        int64_t r = line_off[lo + 1] - p;
+        rem[p] = (uint8_t)(r > 255 ? 255 : r);
     }
-    int64_t r = line_off[lo + 1] - p;
-    rem[p] = (uint8_t)(r > 255 ? 255 : r);
 }
 
 // ----------------------------------------------------------------------------------------------------------
@@ -332,10 +333,12 @@ __device__ __forceinline__ void probe_sparse(const VocabDev& v, uint32_t cand, c
     }
 }
 
-template <int NW>
+// NW = 8-byte key words compared, ML = longest length hashed and probed (max_len <= ML <= 8 * NW): the instantiation
+// for max_len 17 hashes 16 prefix lengths, not the 23 a 24-byte window would allow.
+template <int NW, int ML = 8 * NW>
 __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ corpus, const uint8_t* __restrict__ rem,
                                                     int64_t pos0, uint32_t count, VocabDev v, uint2* __restrict__ M) {
-    constexpr int ML = 8 * NW;
+    static_assert(ML <= 8 * NW && ML > 8 * (NW - 1), "ML must need exactly NW key words");
     constexpr int WDW = (64 + ML + 8) / 4 + 1;   // dwords of text one wave stages for its 64 positions (<= 27)
     __shared__ uint32_t bloom[SAGE_BLOOM_BITS / 32];
     __shared__ uint32_t text_all[16 * 32];
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ 
         Top2 top{0u, 0u};
         // chunks from the longest lengths down.  A chunk runs if ANY lane of the wave still needs it (wave-uniform
         // branch); lanes that do not take part are masked through their candidate bits, not through EXEC.
-        if constexpr (NW >= 2) probe_sparse<NW, 9, ML, ML>(v, cand, fh, W, top);
+        if constexpr (ML >= 9) probe_sparse<NW, 9, ML, ML>(v, cand, fh, W, top);
         {
             const uint32_t c1 = top.m2 == 0u ? cand : 0u;
             if (__any((c1 & 0xF0u) != 0u)) probe_chunk<NW, 5, 8, ML>(v, c1, fh, W, top);

@@ -42,6 +42,57 @@ __device__ __forceinline__ void acc_add_u32(uint32_t* cid, uint32_t* cval, unsig
 }
 
 // ----------------------------------------------------------------------------------------------------------
+// Deterministic mode (sage_set_deterministic): every log-sigmoid term is turned into a 128-bit fixed-point number
+// (units of 2^-60) BEFORE anything is added, and all sums -- per thread, per occurrence, per workgroup, per ablated id
+// -- are integer additions, which commute exactly: the loss vector no longer depends on the order in which atomics
+// land, on the batch size or on how a workgroup's dots are cut into slices.  Terms that are not finite (a caller's NaN
+// or infinite embedding value) bypass it and go straight into the float64 vector, where NaN + x = NaN in any order.
+// ----------------------------------------------------------------------------------------------------------
+struct Fix128 {
+    unsigned long long lo;
+    long long hi;
+};
+#define FIX_LIMIT 5.0e17    // |x| below 2^59: the fixed-point form holds it (and millions of such terms) without overflow
+__device__ __forceinline__ Fix128 fix_from(double x) {      // x finite, |x| < FIX_LIMIT; truncates below 2^-60
+    const double q = floor(x * 0.0625);
+    const double rem = fma(-16.0, q, x);                    // exact, in [0, 16)
+    return Fix128{(unsigned long long)(rem * 1152921504606846976.0), (long long)q};
+}
+__device__ __forceinline__ void fix_add(Fix128& a, const Fix128 b) {
+    a.lo += b.lo;
+    a.hi += b.hi + (a.lo < b.lo ? 1 : 0);
+}
+__device__ __forceinline__ Fix128 fix_neg(const Fix128 a) {
+    return Fix128{~a.lo + 1ull, ~a.hi + (a.lo == 0ull ? 1 : 0)};
+}
+__device__ __forceinline__ Fix128 fix_twice(const Fix128 a) {
+    return Fix128{a.lo << 1, (long long)(((unsigned long long)a.hi << 1) | (a.lo >> 63))};
+}
+// the same addition on two 64-bit words in LDS or global memory: the carry out of the low word is added exactly once
+__device__ __forceinline__ void fix_atomic_add(unsigned long long* lo, unsigned long long* hi, const Fix128 v) {
+    const unsigned long long old = atomicAdd(lo, v.lo);
+    const unsigned long long carry = (old + v.lo) < old ? 1ull : 0ull;
+    const unsigned long long add_hi = (unsigned long long)v.hi + carry;
+    if (add_hi) atomicAdd(hi, add_hi);
+}
+__device__ __forceinline__ void acc_add_fix(uint32_t* cid, unsigned long long* clo, unsigned long long* chi,
+                                            unsigned long long* __restrict__ global /* [id][2] */, uint32_t id, const Fix128 v) {
+    const uint32_t s = acc_slot(id);
+    uint32_t cur = cid[s];
+    if (cur == ACC_EMPTY) cur = atomicCAS(&cid[s], ACC_EMPTY, id), cur = (cur == ACC_EMPTY) ? id : cur;
+    if (cur == id) fix_atomic_add(&clo[s], &chi[s], v);
+    else fix_atomic_add(&global[2 * (size_t)id], &global[2 * (size_t)id + 1], v);
+}
+// loss[i] += the fixed-point sum of id i (end of a deterministic step)
+__global__ void k_fix_finish(const unsigned long long* __restrict__ fix, uint32_t n, double* __restrict__ loss) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long lo = fix[2 * (size_t)i];
+    const long long hi = (long long)fix[2 * (size_t)i + 1];
+    loss[i] += (double)hi * 16.0 + (double)lo * (1.0 / 1152921504606846976.0);
+}
+
+// ----------------------------------------------------------------------------------------------------------
 // Descriptor of one occurrence (16 u32).  Inline form: word 0 = VALID | k | m<<12 | pl<<24 | pr<<26 | NEVER, words
 // 1..15 = the ablated window [left pads | x1..xk | right pads].  Pooled form (window longer than 15 ids, or a base
 // span longer than 4095 tokens): word 0 = VALID | OVER | pl | pr | NEVER, word 1 = offset of the window in the id
@@ -610,27 +661,36 @@ __global__ __launch_bounds__(256) void k_dots(const uint4* __restrict__ desc, co
 #define LOGSIG_TILE 256
 #define LOGSIG_PF 8      // dots of a thread's slice loaded ahead (a tile of 256 occurrences has ~8 dots per thread)
 #define LOGSIG_WIN 6     // pair-cache entries t-2 .. t+3 loaded ahead (centres of up to 4 base tokens)
+template <bool DET>
 __global__ __launch_bounds__(256) void k_logsig(const uint4* __restrict__ desc, const uint32_t* __restrict__ occ_tok,
                                                 const uint32_t* __restrict__ occ_a, uint32_t n_occ,
                                                 const uint32_t* __restrict__ dot_off, const double* __restrict__ dots,
                                                 const double2* __restrict__ Gc, double* __restrict__ loss,
+                                                unsigned long long* __restrict__ loss_fix /* DET: [vsize][2] fixed-point sums */,
                                                 const uint32_t* __restrict__ inex_count, unsigned long long* __restrict__ stats) {
     // Every dot is in place when this runs: with float32 row storage k_describe has split the occurrences, the ones
     // whose rows the float32 copy holds exactly got their dots from it, the others from the float64 matrix.  A NaN dot
     // is therefore the caller's own NaN (or inf * 0) and goes into the loss as the reference's would.
     if (inex_count && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[STAT_INEXACT], (unsigned long long)*inex_count);
     __shared__ uint32_t acc_id[ACC_SLOTS];
-    __shared__ double acc_val[ACC_SLOTS];
+    __shared__ unsigned long long acc_w0[ACC_SLOTS];               // float64 sums, or the low words of the fixed-point sums
+    __shared__ unsigned long long acc_w1[DET ? ACC_SLOTS : 1];     // DET: the high words
     __shared__ uint32_t off[LOGSIG_TILE + 1];
-    __shared__ double osum[LOGSIG_TILE];
-    for (uint32_t i = threadIdx.x; i < ACC_SLOTS; i += 256) { acc_id[i] = ACC_EMPTY; acc_val[i] = 0.0; }
+    __shared__ unsigned long long osum0[LOGSIG_TILE];
+    __shared__ unsigned long long osum1[DET ? LOGSIG_TILE : 1];
+    double* acc_val = reinterpret_cast<double*>(acc_w0);
+    double* osum = reinterpret_cast<double*>(osum0);
+    for (uint32_t i = threadIdx.x; i < ACC_SLOTS; i += 256) { acc_id[i] = ACC_EMPTY; acc_w0[i] = 0ull; if (DET) acc_w1[i] = 0ull; }
     const double* Gd = reinterpret_cast<const double*>(Gc);
+    // DET: a term that is not finite cannot be held in fixed point; it goes into the float64 vector of its ablated id
+    auto stray = [&](uint32_t o, double term) { unsafeAtomicAdd(&loss[occ_a[o] & SAGE_ID_MASK], term); };
     for (uint32_t o0 = blockIdx.x * LOGSIG_TILE; o0 < n_occ; o0 += gridDim.x * LOGSIG_TILE) {
         const uint32_t nt = min((uint32_t)LOGSIG_TILE, n_occ - o0);   // occurrences of this tile
         __syncthreads();
         if (threadIdx.x < nt) off[threadIdx.x] = dot_off[o0 + threadIdx.x];
         if (threadIdx.x == 0) off[nt] = dot_off[o0 + nt];   // nt can be 256: there is no thread 256
-        osum[threadIdx.x] = 0.0;
+        osum0[threadIdx.x] = 0ull;
+        if (DET) osum1[threadIdx.x] = 0ull;
         // phase-2 operands are independent of phase 1: issue their loads first
         const uint32_t o = o0 + threadIdx.x;
         uint4 h = make_uint4(0, 0, 0, 0);
@@ -667,21 +727,27 @@ __global__ __launch_bounds__(256) void k_logsig(const uint4* __restrict__ desc, 
         double v[LOGSIG_PF];
 #pragma unroll
         for (int q = 0; q < LOGSIG_PF; ++q) v[q] = (i + q < iend) ? dots[i + q] : 0.0;
+        // base-window sum of this thread's occurrence: a float64 sum, or (DET) a fixed-point sum of its terms
         double sb = 0.0;
+        Fix128 sbf{0ull, 0};
+        auto base_term = [&](double g) {
+            if (!DET) { sb += g; return; }
+            if (fabs(g) < FIX_LIMIT) fix_add(sbf, fix_from(g)); else stray(o, 2.0 * g);
+        };
         if (live) {
             if (small) {
 #pragma unroll
-                for (int q = 1; q < LOGSIG_WIN; ++q) { const int rel = q - 2; sb += (rel >= lo1 && rel <= hi1) ? W[q].x : 0.0; }
+                for (int q = 1; q < LOGSIG_WIN; ++q) { const int rel = q - 2; if (rel >= lo1 && rel <= hi1) base_term(W[q].x); }
 #pragma unroll
                 for (int q = 0; q < LOGSIG_WIN; ++q) {
                     const int rel = q - 2;
                     const bool in = rel >= lo2 && rel <= hi2 && ((rel >= 0 && rel <= im - 1) || (rel + 2 >= 0 && rel + 2 <= im - 1));
-                    sb += in ? W[q].y : 0.0;
+                    if (in) base_term(W[q].y);
                 }
             } else {
-                for (int rel = lo1; rel <= hi1; ++rel) sb += Gd[((size_t)t + rel) * 2];
+                for (int rel = lo1; rel <= hi1; ++rel) base_term(Gd[((size_t)t + rel) * 2]);
                 for (int rel = lo2; rel <= hi2; ++rel)
-                    if ((rel >= 0 && rel <= im - 1) || (rel + 2 >= 0 && rel + 2 <= im - 1)) sb += Gd[((size_t)t + rel) * 2 + 1];
+                    if ((rel >= 0 && rel <= im - 1) || (rel + 2 >= 0 && rel + 2 <= im - 1)) base_term(Gd[((size_t)t + rel) * 2 + 1]);
             }
         }
         if (i < iend) {
@@ -693,11 +759,16 @@ __global__ __launch_bounds__(256) void k_logsig(const uint4* __restrict__ desc, 
             }
             uint32_t own = lo, nxt = off[own + 1];
             double acc = 0.0;
+            Fix128 accf{0ull, 0};
+            auto hand_over = [&]() {
+                if (!DET) unsafeAtomicAdd(&osum[own], acc);
+                else if (accf.lo | (unsigned long long)accf.hi) fix_atomic_add(&osum0[own], &osum1[own], accf);
+                acc = 0.0; accf = Fix128{0ull, 0};
+            };
             uint32_t q = 0;
             for (; i < iend; ++i, ++q) {
                 if (i >= nxt) {
-                    unsafeAtomicAdd(&osum[own], acc);
-                    acc = 0.0;
+                    hand_over();
                     do { ++own; nxt = off[own + 1]; } while (i >= nxt);
                 }
                 double x;
@@ -708,15 +779,28 @@ __global__ __launch_bounds__(256) void k_logsig(const uint4* __restrict__ desc, 
                 } else {
                     x = dots[i];
                 }
-                acc += log_sigmoid(x);
+                const double ls = log_sigmoid(x);
+                if (!DET) acc += ls;
+                else if (fabs(ls) < FIX_LIMIT) fix_add(accf, fix_from(ls));
+                else stray(o0 + own, -2.0 * ls);
             }
-            unsafeAtomicAdd(&osum[own], acc);
+            hand_over();
         }
         __syncthreads();
-        if (live) acc_add_f64(acc_id, acc_val, loss, SAGE_T_ID(a_w0), -2.0 * (osum[threadIdx.x] - sb));
+        if (live) {
+            if (!DET) {
+                acc_add_f64(acc_id, acc_val, loss, SAGE_T_ID(a_w0), -2.0 * (osum[threadIdx.x] - sb));
+            } else {      // -2 * (ablated - base) = 2 * (base - ablated), all in fixed point
+                Fix128 tot = sbf;
+                fix_add(tot, fix_neg(Fix128{osum0[threadIdx.x], (long long)osum1[threadIdx.x]}));
+                acc_add_fix(acc_id, acc_w0, acc_w1, loss_fix, SAGE_T_ID(a_w0), fix_twice(tot));
+            }
+        }
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < ACC_SLOTS; i += 256)
-        if (acc_id[i] != ACC_EMPTY) unsafeAtomicAdd(&loss[acc_id[i]], acc_val[i]);
+        if (acc_id[i] != ACC_EMPTY) {
+            if (!DET) unsafeAtomicAdd(&loss[acc_id[i]], acc_val[i]);
+            else fix_atomic_add(&loss_fix[2 * (size_t)acc_id[i]], &loss_fix[2 * (size_t)acc_id[i] + 1], Fix128{acc_w0[i], (long long)acc_w1[i]});
+        }
 }
-

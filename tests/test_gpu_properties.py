@@ -93,3 +93,29 @@ def test_repeatable(world):
     eng, vocab, corpus, off, emb, bounds, ref = world
     again = eng.ablation_step(bounds)
     _same(ref, again, rtol=1e-12)
+
+
+def test_deterministic_mode_is_bit_identical(world):
+    """sage_set_deterministic: fixed-point sums make the loss vector bit-identical from run to run, for any batch size
+    and for both row storage modes' shared terms; it agrees with the default float64-atomic sums to rounding."""
+    eng, vocab, corpus, off, emb, bounds, ref = world
+    eng.set_deterministic(True)
+    try:
+        a = eng.ablation_step(bounds)
+        b = eng.ablation_step(bounds)
+        assert np.array_equal(a[0], b[0])
+        eng.set_batch_bytes(8 << 20)                 # many small batches: other tiles, other slices, other atomic orders
+        c = eng.ablation_step(bounds)
+        eng.set_batch_bytes(256 << 20)
+        assert np.array_equal(a[0], c[0])
+        assert a[2] == c[2] and a[3] == c[3] and np.array_equal(a[1], c[1]) and np.array_equal(a[4], c[4])
+        # halves: integer sums add exactly, so the two halves differ from the whole only by the final conversions
+        mid = (len(bounds) - 1) // 2
+        h1, h2 = eng.ablation_step(bounds[:mid + 1]), eng.ablation_step(bounds[mid:])
+        np.testing.assert_allclose(h1[0] + h2[0], a[0], rtol=1e-13, atol=1e-13 * np.abs(a[0]).max())
+        _same(ref, a, rtol=1e-10)                    # the default mode's sums, to float64 rounding
+    finally:
+        eng.set_deterministic(False)
+        eng.set_batch_bytes(256 << 20)
+    d = eng.ablation_step(bounds)
+    _same(ref, d, rtol=1e-12)
