@@ -64,6 +64,8 @@ class SaGeVocabBuilder:
         # the ablation step; None = run_sage_parallel on one GPU, run_sage_distributed under torch.distributed
         self.run_step = None
         self.near_ties: Dict[int, tuple] = {}   # target size -> (pruned side, kept side) of a near-tie at the cut
+        # fixed-point loss sums: bit-identical losses from run to run (sage_set_deterministic); SAGE_DETERMINISTIC=1 too
+        self.deterministic = False
 
     # ---- one round: score, choose the cut, write the files -------------------------------------------------------
     def _step_fn(self):
@@ -91,6 +93,9 @@ class SaGeVocabBuilder:
         if self.max_len != longest:
             logging.warning(f"max_len={self.max_len} differs from the longest key ({longest} bytes)")
         sage_model = SaGeTokenizer(byte_vocab, self.max_len)
+        if self.deterministic:
+            from .parallel import get_engine
+            get_engine().set_deterministic(True)
         partial_corpus = hostio.load_corpus_for_rank(corpus_filepath, partial_corpus_filepath,
                                                      partial_corpus_line_number, rank)
 

@@ -11,6 +11,7 @@ bit-identical to a reference run with that many workers.
 from __future__ import annotations
 
 import logging
+import os
 from typing import Dict, Iterable, List, Sequence, Tuple
 
 import numpy as np
@@ -61,6 +62,8 @@ def get_engine(device: int | None = None) -> HipSage:
     dev = current_device() if device is None else device
     if dev not in _engines:
         _engines[dev] = HipSage(dev)
+        if os.environ.get("SAGE_DETERMINISTIC", "") not in ("", "0"):
+            _engines[dev].set_deterministic(True)
     return _engines[dev]
 
 
