@@ -140,7 +140,10 @@ int sage_get_kernel_times(sage_ctx* ctx, double* out_ms /*[SAGE_K_NCLASSES]*/, i
 /* Tunables: scratch is sized for batches of at most `bytes` corpus bytes (default 256 MiB). */
 int sage_set_batch_bytes(sage_ctx* ctx, int64_t bytes);
 
-/* Matcher variant: 0 = persistent blocks with the 128 KiB presence filter in LDS (default), 1 = plain. */
+/* Matcher variant: 0 = persistent blocks with the 128 KiB presence filter in LDS, candidates compacted through an LDS
+   queue and probed in the embedded-key table (default); 1 = plain (every length probed in the slot table + key planes);
+   2 = the LDS filter with column-by-column probes of the slot table + key planes.  Identical results; 1 and 2 are the
+   cross-checks of the tests (different tables, different probe code). */
 int sage_set_match_mode(sage_ctx* ctx, int mode);
 
 /* Distinct-key counting back end: 0 = hash partition + LDS dedupe (default), 1 = per-segment sets in HBM (the

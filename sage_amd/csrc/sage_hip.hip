@@ -61,8 +61,9 @@ struct sage_ctx {
     std::string err;
 
     // vocabulary
-    DevBuf buckets, keys, byte_id, direct2, bloom, pmask, pmask8;
-    int match_mode = 0;  // 0 = LDS-filtered persistent matcher, 1 = plain matcher
+    DevBuf buckets, keys, byte_id, direct2, bloom, pmask, pmask8, ebk;
+    uint32_t enb = 0;
+    int match_mode = 0;  // 0 = LDS-filtered persistent matcher with queued probes, 1 = plain matcher, 2 = LDS-filtered with column probes
     uint32_t bucket_mask = 0, key_plane = 0;
     int max_len = 0;
     int64_t max_id = -1;
@@ -237,14 +238,17 @@ struct MatchBufs {
 // grand_total[0] = tokens, grand_total[1] = ablated occurrences (device).  Launches only: nothing is allocated.
 void launch_match_and_count(sage_ctx* c, const MatchBufs& B, int64_t line0, uint32_t nl, int64_t pos0, uint64_t nb) {
     VocabDev v{c->buckets.as<uint4>(), c->bucket_mask, c->keys.as<uint64_t>(), c->key_plane, c->byte_id.as<uint32_t>(),
-               c->direct2.as<uint32_t>(), c->bloom.as<uint32_t>(), c->pmask.p, c->pmask8.p, c->max_len};
+               c->direct2.as<uint32_t>(), c->bloom.as<uint32_t>(), c->pmask.p, c->pmask8.p, c->max_len,
+               c->ebk.as<uint4>(), c->enb};
     if (nb) {
         Prof p(c, SAGE_K_MATCH);
         const uint32_t grid = cdiv(nb, 256);
         const int nw = (c->max_len + 7) / 8;
-        if (c->match_mode == 0) {
+        if (c->match_mode != 1) {
             const uint32_t pgrid = std::min<uint32_t>(cdiv(nb, 1024), (uint32_t)c->n_cu);
-#define SAGE_MATCH_LDS(NW_, ML_) k_match_lds<NW_, ML_><<<pgrid, 1024, 0, c->stream>>>(B.corpus, B.rem, pos0, (uint32_t)nb, v, B.M)
+#define SAGE_MATCH_LDS(NW_, ML_) do { \
+                if (c->match_mode == 0) k_match_lds<NW_, ML_, true><<<pgrid, 1024, 0, c->stream>>>(B.corpus, B.rem, pos0, (uint32_t)nb, v, B.M); \
+                else k_match_lds<NW_, ML_, false><<<pgrid, 1024, 0, c->stream>>>(B.corpus, B.rem, pos0, (uint32_t)nb, v, B.M); } while (0)
             const int ml = c->max_len;      // the smallest instantiation that covers max_len
             if (ml <= 8) SAGE_MATCH_LDS(1, 8);
             else if (ml <= 12) SAGE_MATCH_LDS(2, 12);
@@ -794,6 +798,18 @@ int sage_set_vocab(sage_ctx* c, const uint8_t* key_bytes, const int64_t* key_off
     std::vector<uint32_t> bloom(SAGE_BLOOM_BITS / 32, 0u);
     std::vector<uint32_t> pmask(SAGE_PMASK_SLOTS, 0u), pmask8(SAGE_PMASK8_SLOTS, 0u);
     const uint32_t bmask = (uint32_t)(nbuckets - 1);
+    // embedded-key table (VocabDev::ebk): keys of 3..max_len bytes, load <= 0.25 unless SAGE_ETABLE_LOAD says otherwise
+    int64_t n_long = 0;
+    for (int64_t i = 0; i < n_keys; ++i) {
+        const int64_t len = key_offsets[i + 1] - key_offsets[i];
+        n_long += len >= 3 && len <= max_len;
+    }
+    double eload = 0.25;
+    if (const char* e = std::getenv("SAGE_ETABLE_LOAD")) { const double x = std::atof(e); if (x >= 0.05 && x <= 0.9) eload = x; }
+    const uint32_t enb = (uint32_t)std::max<int64_t>(16, (int64_t)std::ceil((double)n_long / (4.0 * eload)));
+    std::vector<uint32_t> etab((size_t)enb * 16, 0u);
+    for (uint32_t b = 0; b < enb; ++b)
+        for (int q = 0; q < 4; ++q) etab[(size_t)b * 16 + 8 + q] = SAGE_SLOT_EMPTY;
     for (int64_t i = 0; i < n_keys; ++i) {
         const uint32_t id = (uint32_t)(key_ids ? key_ids[i] : i);
         const uint8_t* k = key_bytes + key_offsets[i];
@@ -824,6 +840,23 @@ int sage_set_vocab(sage_ctx* c, const uint8_t* key_bytes, const int64_t* key_off
             if (q < 4) { s[q] = sage_slot_make(id, len, f); break; }
             b = (b + 1) & bmask;
         }
+        if (len >= 3) {
+            uint8_t kb[12] = {0};
+            std::memcpy(kb, k, std::min<uint32_t>(len, 12u));
+            uint32_t eb = (uint32_t)(((uint64_t)f * enb) >> 32);
+            for (;;) {
+                uint32_t* s = &etab[(size_t)eb * 16];
+                int q = 0;
+                while (q < 4 && s[8 + q] != SAGE_SLOT_EMPTY) ++q;
+                if (q < 4) {
+                    std::memcpy(&s[2 * q], kb, 8);
+                    s[8 + q] = id | ((len - 1u) << 20);
+                    std::memcpy(&s[12 + q], kb + 8, 4);
+                    break;
+                }
+                eb = eb + 1u == enb ? 0u : eb + 1u;
+            }
+        }
     }
     for (int b = 0; b < 256; ++b)
         if (byte_id[b] == SAGE_SLOT_EMPTY) {
@@ -834,6 +867,7 @@ int sage_set_vocab(sage_ctx* c, const uint8_t* key_bytes, const int64_t* key_off
     int rc;
     if ((rc = ensure(c, c->buckets, slots.size() * 4))) return rc;
     if ((rc = ensure(c, c->keys, keys.size() * 8))) return rc;
+    if ((rc = ensure(c, c->ebk, etab.size() * 4))) return rc;
     if ((rc = ensure(c, c->byte_id, 256 * 4))) return rc;
     if ((rc = ensure(c, c->direct2, direct2.size() * 4))) return rc;
     if ((rc = ensure(c, c->bloom, bloom.size() * 4))) return rc;
@@ -842,6 +876,7 @@ int sage_set_vocab(sage_ctx* c, const uint8_t* key_bytes, const int64_t* key_off
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(c->buckets.p, slots.data(), slots.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->keys.p, keys.data(), keys.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->ebk.p, etab.data(), etab.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->byte_id.p, byte_id.data(), 256 * 4, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->direct2.p, direct2.data(), direct2.size() * 4, hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(c->bloom.p, bloom.data(), bloom.size() * 4, hipMemcpyHostToDevice));
@@ -854,6 +889,7 @@ int sage_set_vocab(sage_ctx* c, const uint8_t* key_bytes, const int64_t* key_off
         HIP_TRY(c, hipMemcpy(c->pmask8.p, pmask8.data(), pmask8.size() * 4, hipMemcpyHostToDevice));
     }
     c->bucket_mask = bmask;
+    c->enb = enb;
     c->key_plane = (uint32_t)key_plane;
     c->max_len = max_len;
     c->max_id = max_id;
@@ -1261,7 +1297,7 @@ int sage_set_batch_bytes(sage_ctx* c, int64_t bytes) {
 }
 
 int sage_set_match_mode(sage_ctx* c, int mode) {
-    if (!c || (mode != 0 && mode != 1)) return fail(c, SAGE_E_ARG, "match mode must be 0 or 1");
+    if (!c || mode < 0 || mode > 2) return fail(c, SAGE_E_ARG, "match mode must be 0, 1 or 2");
     c->match_mode = mode;
     return SAGE_OK;
 }

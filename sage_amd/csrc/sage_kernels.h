@@ -19,6 +19,10 @@ struct VocabDev {
                               // uint16 entries when max_len <= 16 (half the cache footprint), else uint32
     const void* pmask8;       // [SAGE_PMASK8_SLOTS] the same for the first 8 bytes (keys of >= 8 bytes)
     int max_len;
+    const uint4* ebk;         // embedded-key table of the queued matcher: one 64-byte bucket = 4 slots as
+                              // {u64 first 8 key bytes [4]; u32 id | (len-1) << 20 [4]; u32 key bytes 8..11 [4]}, keys of >= 3 bytes.
+                              // A probe is ONE cache-line request: keys of <= 12 bytes are verified from the bucket itself
+    uint32_t enb;             // buckets of ebk (any number; bucket = mulhi(hash, enb))
 };
 
 enum { FLAG_SET_OVERFLOW = 0, FLAG_ROW_OOB = 1, FLAG_EMPTY_LINE = 2, FLAG_COUNT = 8 };
@@ -333,15 +337,138 @@ __device__ __forceinline__ void probe_sparse(const VocabDev& v, uint32_t cand, c
     }
 }
 
+// exact serial probe of one length in the embedded-key table (any chain length): every slot of the right length whose
+// first 8 bytes match is verified against the key planes
+template <int NW>
+__device__ __forceinline__ bool probe_exact_e(const VocabDev& v, uint32_t b, const uint64_t (&W)[NW], uint32_t j, uint32_t& hid) {
+    const uint32_t sh0 = 64u - 8u * min(j, 8u);
+    for (;;) {
+        const uint4* bp = v.ebk + (size_t)b * 4u;
+        const uint4 k01 = bp[0], k23 = bp[1], meta = bp[2];
+        const uint64_t key[4] = {(uint64_t)k01.x | ((uint64_t)k01.y << 32), (uint64_t)k01.z | ((uint64_t)k01.w << 32),
+                                 (uint64_t)k23.x | ((uint64_t)k23.y << 32), (uint64_t)k23.z | ((uint64_t)k23.w << 32)};
+        const uint32_t mt[4] = {meta.x, meta.y, meta.z, meta.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if ((mt[t] >> 20) == j - 1u && ((key[t] ^ W[0]) << (sh0 & 63u)) == 0ull) {
+                const uint32_t cnd = mt[t] & SAGE_ID_MASK;
+                if (j <= 8u || key_equal_mem<NW>(v, W, cnd, (int)j)) { hid = cnd; return true; }
+            }
+        }
+        if (meta.w == SAGE_SLOT_EMPTY) return false;
+        b = b + 1u == v.enb ? 0u : b + 1u;
+    }
+}
+
+// Queued probe (the default): column-by-column probing spends a probe slot per lane and length whether or not the lane
+// has a candidate there (about 10 slots per position for 3-4 candidates).  Here the (position, length) candidates of a
+// length class are compacted into a per-wave LDS queue, longest length first (a ballot per length gives every lane its
+// entry index without a scan), and the wave then probes 64 REAL candidates per round: lane e takes entry e, fetches
+// the text words of the entry's position from the owner lane's registers (ds_bpermute), probes, and leaves the result
+// in the entry; the owners fold their results afterwards.  A class larger than the queue is done in windows.
+#define MQ_CAP 224u      // entries per wave: 16 waves x 224 x 8 B = 28 KiB beside the 128 KiB filter
+template <int NW, int JLO, int JHI, int ML>
+__device__ __forceinline__ void probe_queued(const VocabDev& v, uint32_t cand, const uint32_t (&fh)[ML + 1],
+                                             const uint64_t (&W)[NW], Top2& top, uint2* __restrict__ q, uint32_t lane) {
+    constexpr int N = JHI - JLO + 1;
+    constexpr int KW = (JHI + 7) / 8;          // key words a length of this class can reach
+    const uint32_t c = top.m2 == 0u ? cand : 0u;
+    uint32_t pre[N];                            // queue index of this lane's entry for length JHI - i
+    uint32_t total = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int j = JHI - i;
+        const unsigned long long m = __ballot((c >> (j - 1)) & 1u);
+        pre[i] = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        total += (uint32_t)__popcll(m);
+    }
+    for (uint32_t w0 = 0; w0 < total; w0 += MQ_CAP) {        // wave-uniform
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int j = JHI - i;
+            if (((c >> (j - 1)) & 1u) && pre[i] - w0 < MQ_CAP) q[pre[i] - w0] = make_uint2(fh[j], lane | ((uint32_t)j << 6));
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t n = min(total - w0, MQ_CAP);
+        for (uint32_t e0 = 0; e0 < n; e0 += 64u) {
+            const uint32_t e = e0 + lane;
+            const bool valid = e < n;
+            const uint2 ent = q[valid ? e : 0u];
+            const uint32_t f = ent.x, src = ent.y & 63u, j = ent.y >> 6;
+            const uint32_t b = valid ? __umulhi(f, v.enb) : 0u;
+            const uint4* bp = v.ebk + (size_t)b * 4u;
+            const uint4 k01 = bp[0], k23 = bp[1], meta = bp[2];
+            uint4 ext = make_uint4(0u, 0u, 0u, 0u);
+            if (JHI > 8) ext = bp[3];
+            uint64_t Ws[NW];
+#pragma unroll
+            for (int k = 0; k < NW; ++k) {
+                if (k < KW) {
+                    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)W[k], (int)src, 64);
+                    const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(W[k] >> 32), (int)src, 64);
+                    Ws[k] = (uint64_t)lo | ((uint64_t)hi << 32);
+                } else Ws[k] = 0ull;
+            }
+            // slot t matches when its length is j and its stored bytes (8, or 12 for the long class) equal the text's.
+            // All of the bucket is loaded at once (3-4 requests to ONE line): fetching only the slot whose length fits,
+            // after a look at the lengths, makes the second load wait for the first and measured 22 % slower.
+            const uint32_t lenw = j - 1u;
+            const uint32_t sh0 = JLO > 8 ? 0u : 64u - 8u * min(j, 8u);
+            const uint64_t key[4] = {(uint64_t)k01.x | ((uint64_t)k01.y << 32), (uint64_t)k01.z | ((uint64_t)k01.w << 32),
+                                     (uint64_t)k23.x | ((uint64_t)k23.y << 32), (uint64_t)k23.z | ((uint64_t)k23.w << 32)};
+            const uint32_t mt[4] = {meta.x, meta.y, meta.z, meta.w};
+            const uint32_t ex[4] = {ext.x, ext.y, ext.z, ext.w};
+            uint32_t she = 0, w1 = 0;
+            if (JHI > 8) { she = 32u - 8u * min(max(j, 9u) - 8u, 4u); w1 = (uint32_t)Ws[NW > 1 ? 1 : 0]; }
+            bool hit = false;
+            uint32_t id = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                bool m = (mt[t] >> 20) == lenw && ((key[t] ^ Ws[0]) << (sh0 & 63u)) == 0ull;
+                if (JHI > 8) m = m && (j <= 8u || ((ex[t] ^ w1) << she) == 0u);
+                id = m ? (mt[t] & SAGE_ID_MASK) : id;
+                hit = hit || m;
+            }
+            bool eq = valid && hit;
+            // keys of more than 12 bytes: the rest of the key from the planes (a second request, rare)
+            if (JHI > 12) {
+                if (eq && j > 12u) {
+#pragma unroll
+                    for (int k = 1; k < NW; ++k) {
+                        const int nb = (int)j - 8 * k;
+                        if (nb > 0) {
+                            const uint64_t kk = v.keys[(size_t)k * v.key_plane + id];
+                            const uint32_t sh = 64u - 8u * (uint32_t)min(nb, 8);
+                            eq = eq && ((Ws[k] ^ kk) << (sh & 63u)) == 0ull;
+                        }
+                    }
+                    hit = true;   // (a failed verification falls to the exact probe below)
+                }
+            }
+            // rare: the bucket is full (the key may live in the next one), or a 12-byte prefix matched a different key
+            if (valid && !eq && (hit || meta.w != SAGE_SLOT_EMPTY)) eq = probe_exact_e<NW>(v, b, Ws, j, id);
+            if (valid) q[e].x = eq ? (id | (j << 20)) : 0u;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int j = JHI - i;
+            if (((c >> (j - 1)) & 1u) && pre[i] - w0 < MQ_CAP) top.fold(q[pre[i] - w0].x);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // NW = 8-byte key words compared, ML = longest length hashed and probed (max_len <= ML <= 8 * NW): the instantiation
 // for max_len 17 hashes 16 prefix lengths, not the 23 a 24-byte window would allow.
-template <int NW, int ML = 8 * NW>
+template <int NW, int ML = 8 * NW, bool QUEUED = true>
 __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ corpus, const uint8_t* __restrict__ rem,
                                                     int64_t pos0, uint32_t count, VocabDev v, uint2* __restrict__ M) {
     static_assert(ML <= 8 * NW && ML > 8 * (NW - 1), "ML must need exactly NW key words");
     constexpr int WDW = (64 + ML + 8) / 4 + 1;   // dwords of text one wave stages for its 64 positions (<= 27)
     __shared__ uint32_t bloom[SAGE_BLOOM_BITS / 32];
     __shared__ uint32_t text_all[16 * 32];
+    __shared__ uint2 mq_all[QUEUED ? 16 * MQ_CAP : 1];
     const uint32_t tid = threadIdx.x;
     {
         const uint4* src4 = reinterpret_cast<const uint4*>(v.bloom);
@@ -373,7 +500,8 @@ __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ 
         if (lane < (uint32_t)WDW) text[lane] = tw;
         __builtin_amdgcn_wave_barrier();
         const uint32_t rel = tile * 64u + lane;
-        if (rel >= count) continue;
+        // a lane past the end has rm = 0, hence no candidates; in the queued form it stays to serve cross-lane reads
+        if (!QUEUED && rel >= count) continue;
         const uint32_t o = (uint32_t)(blk0 & 3) + lane;
         const uint32_t wi = o >> 2, sh = (o & 3u) * 8u;
         uint32_t T[2 * NW];
@@ -412,8 +540,16 @@ __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ 
         Top2 top{0u, 0u};
         // chunks from the longest lengths down.  A chunk runs if ANY lane of the wave still needs it (wave-uniform
         // branch); lanes that do not take part are masked through their candidate bits, not through EXEC.
-        if constexpr (ML >= 9) probe_sparse<NW, 9, ML, ML>(v, cand, fh, W, top);
-        {
+        if constexpr (QUEUED) {
+            uint2* q = mq_all + (tid >> 6) * MQ_CAP;
+            if constexpr (ML >= 9) {
+                if (__any((cand >> 8) != 0u)) probe_queued<NW, 9, ML, ML>(v, cand, fh, W, top, q, lane);
+            }
+            // (one class 3..8 saves a round trip but loses the early stop between 5..8 and 3..4: 7.56 vs 7.03 ms per 152 MB)
+            probe_queued<NW, 5, 8, ML>(v, cand, fh, W, top, q, lane);
+            probe_queued<NW, 3, 4, ML>(v, cand, fh, W, top, q, lane);
+        } else {
+            if constexpr (ML >= 9) probe_sparse<NW, 9, ML, ML>(v, cand, fh, W, top);
             const uint32_t c1 = top.m2 == 0u ? cand : 0u;
             if (__any((c1 & 0xF0u) != 0u)) probe_chunk<NW, 5, 8, ML>(v, c1, fh, W, top);
             const uint32_t c2 = top.m2 == 0u ? cand : 0u;
@@ -427,7 +563,8 @@ __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ 
         // longest of them in any case; with a single match m2 is 0 = "no second match", len2 == 0 iff len1 == 1)
         // streamed once: keep it out of the way of the table and key planes in L2
         const uint32_t ends1 = SAGE_M_LEN(top.m1) == rm ? 0x80000000u : 0u;
-        __builtin_nontemporal_store((uint64_t)(top.m1 | ends1) | ((uint64_t)top.m2 << 32), reinterpret_cast<uint64_t*>(M + rel));
+        if (rel < count)
+            __builtin_nontemporal_store((uint64_t)(top.m1 | ends1) | ((uint64_t)top.m2 << 32), reinterpret_cast<uint64_t*>(M + rel));
     }
 }
 

@@ -34,8 +34,8 @@ def test_tokenize_golden(tag):
     assert ids.tolist() == g["ids"].tolist()
     assert starts.tolist() == g["starts"].tolist()
     assert widths.tolist() == g["widths"].tolist()
-    # the plain (unfiltered) matcher gives the same answer
-    for mode in (1,):
+    # the plain (unfiltered) matcher and the column-probe matcher (other table, other probe code) give the same answer
+    for mode in (1, 2):
         eng.set_match_mode(mode)
         ids1, starts1, widths1, counts1 = eng.tokenize(0, len(lines))
         assert ids1.tolist() == ids.tolist() and widths1.tolist() == widths.tolist() and counts1.tolist() == counts.tolist(), mode

@@ -62,11 +62,12 @@ def test_kernel_variants_agree(world):
         _same(ref, eng.ablation_step(bounds))
     finally:
         eng.set_count_mode(0)
-    eng.set_match_mode(1)                                  # unfiltered matcher
-    try:
-        _same(ref, eng.ablation_step(bounds))
-    finally:
-        eng.set_match_mode(0)
+    for mode in (1, 2):                                    # unfiltered matcher; column probes of the slot table
+        eng.set_match_mode(mode)
+        try:
+            _same(ref, eng.ablation_step(bounds))
+        finally:
+            eng.set_match_mode(0)
     eng.set_score_mode(1)                                  # float64 row storage
     eng.set_embeddings(emb)
     try:
