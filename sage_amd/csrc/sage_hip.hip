@@ -62,6 +62,7 @@ struct sage_ctx {
 
     // vocabulary
     DevBuf buckets, keys, byte_id, direct2, bloom, pmask, pmask8, ebk;
+    DevBuf vk_bytes, vk_off, vk_ids;   // packed keys as uploaded (input of k_vocab_build)
     uint32_t enb = 0;
     int match_mode = 0;  // 0 = LDS-filtered persistent matcher with queued probes, 1 = plain matcher, 2 = LDS-filtered with column probes
     uint32_t bucket_mask = 0, key_plane = 0;
@@ -759,7 +760,7 @@ void sage_destroy(sage_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     collect_events(c);
     for (auto e : c->ev_free) (void)hipEventDestroy(e);
-    DevBuf* all[] = {&c->buckets, &c->keys, &c->byte_id, &c->direct2, &c->bloom, &c->pmask, &c->pmask8, &c->corpus, &c->rem, &c->line_off, &c->emb, &c->M, &c->ntok,
+    DevBuf* all[] = {&c->buckets, &c->keys, &c->ebk, &c->vk_bytes, &c->vk_off, &c->vk_ids, &c->byte_id, &c->direct2, &c->bloom, &c->pmask, &c->pmask8, &c->corpus, &c->rem, &c->line_off, &c->emb, &c->M, &c->ntok,
                      &c->tokoff, &c->tile_sums, &c->grand_total, &c->tok_w0, &c->occ_pos, &c->set, &c->seg_line_rel,
                      &c->seg_tok_off, &c->set_base, &c->set_mask, &c->seg_pairs, &c->desc, &c->gcache, &c->bucket_off, &c->rec_a, &c->nocc, &c->occoff, &c->occ_tok,
                      &c->occ_a, &c->exact_list, &c->exact_count, &c->np_ab, &c->dot_off, &c->dots, &c->pool, &c->pool_cursor, &c->np_all, &c->pair_off, &c->seg_first_occ, &c->seg_tile_off,
@@ -787,16 +788,12 @@ int sage_set_vocab(sage_ctx* c, const uint8_t* key_bytes, const int64_t* key_off
         // warns about such a vocabulary, SaGeVocabBuilder.py:52-54): it keeps its id but is left out of every table
         max_id = std::max(max_id, id);
     }
-    std::vector<uint32_t> byte_id(256, SAGE_SLOT_EMPTY);
-    std::vector<uint32_t> direct2(65536, SAGE_SLOT_EMPTY);   // id of every 2-byte key, indexed by its bytes
+    // The tables are built on the GPU (k_vocab_build, one thread per key): only the packed keys travel.
+    const int nw = (max_len + 7) / 8;
     const size_t key_plane = ((size_t)max_id + 1 + 15) & ~(size_t)15;   // ids per 8-byte-word plane
-    std::vector<uint64_t> keys(key_plane * 4, 0);
-    // load factor <= 0.25: a probe of an absent key continues into the next bucket only when this one is full
-    // (2 % of the buckets at this load, 14 % at 0.5), and that continuation is a serial, divergent path in the matcher
+    // slot table: load factor <= 0.25: a probe of an absent key continues into the next bucket only when this one is
+    // full (2 % of the buckets at this load, 14 % at 0.5), and that continuation is a serial, divergent path
     const uint64_t nbuckets = pow2ceil(std::max<uint64_t>(16, (uint64_t)n_keys));
-    std::vector<uint32_t> slots(nbuckets * 4, SAGE_SLOT_EMPTY);
-    std::vector<uint32_t> bloom(SAGE_BLOOM_BITS / 32, 0u);
-    std::vector<uint32_t> pmask(SAGE_PMASK_SLOTS, 0u), pmask8(SAGE_PMASK8_SLOTS, 0u);
     const uint32_t bmask = (uint32_t)(nbuckets - 1);
     // embedded-key table (VocabDev::ebk): keys of 3..max_len bytes, load <= 0.25 unless SAGE_ETABLE_LOAD says otherwise
     int64_t n_long = 0;
@@ -807,87 +804,48 @@ int sage_set_vocab(sage_ctx* c, const uint8_t* key_bytes, const int64_t* key_off
     double eload = 0.25;
     if (const char* e = std::getenv("SAGE_ETABLE_LOAD")) { const double x = std::atof(e); if (x >= 0.05 && x <= 0.9) eload = x; }
     const uint32_t enb = (uint32_t)std::max<int64_t>(16, (int64_t)std::ceil((double)n_long / (4.0 * eload)));
-    std::vector<uint32_t> etab((size_t)enb * 16, 0u);
-    for (uint32_t b = 0; b < enb; ++b)
-        for (int q = 0; q < 4; ++q) etab[(size_t)b * 16 + 8 + q] = SAGE_SLOT_EMPTY;
-    for (int64_t i = 0; i < n_keys; ++i) {
-        const uint32_t id = (uint32_t)(key_ids ? key_ids[i] : i);
-        const uint8_t* k = key_bytes + key_offsets[i];
-        const uint32_t len = (uint32_t)(key_offsets[i + 1] - key_offsets[i]);
-        if (len > (uint32_t)max_len) continue;
-        {
-            uint8_t kb[SAGE_MAX_KEY_LEN] = {0};
-            std::memcpy(kb, k, len);
-            for (int w = 0; w < 4; ++w) std::memcpy(&keys[(size_t)w * key_plane + id], kb + 8 * w, 8);
-        }
-        if (len == 1) { byte_id[k[0]] = id; continue; }  // single bytes are looked up directly
-        if (len == 2) direct2[(uint32_t)k[0] | ((uint32_t)k[1] << 8)] = id;   // (and stay in the hash table for k_match)
-        uint32_t h = SAGE_FNV_OFFSET;
-        for (uint32_t j = 0; j < len; ++j) {
-            h = sage_fnv_step(h, k[j]);
-            if (j == 3) pmask[sage_mix32(h) & (SAGE_PMASK_SLOTS - 1u)] |= 1u << (len - 1u);   // len >= 4 here
-            if (j == 7) pmask8[sage_mix32(h) & (SAGE_PMASK8_SLOTS - 1u)] |= 1u << (len - 1u);  // len >= 8 here
-        }
-        const uint32_t f = sage_mix32(h);
-        {
-            bloom[sage_bloom_word(f)] |= sage_bloom_mask(f);
-        }
-        uint32_t b = f & bmask;
-        for (;;) {
-            uint32_t* s = &slots[(size_t)b * 4];
-            int q = 0;
-            while (q < 4 && s[q] != SAGE_SLOT_EMPTY) ++q;
-            if (q < 4) { s[q] = sage_slot_make(id, len, f); break; }
-            b = (b + 1) & bmask;
-        }
-        if (len >= 3) {
-            uint8_t kb[12] = {0};
-            std::memcpy(kb, k, std::min<uint32_t>(len, 12u));
-            uint32_t eb = (uint32_t)(((uint64_t)f * enb) >> 32);
-            for (;;) {
-                uint32_t* s = &etab[(size_t)eb * 16];
-                int q = 0;
-                while (q < 4 && s[8 + q] != SAGE_SLOT_EMPTY) ++q;
-                if (q < 4) {
-                    std::memcpy(&s[2 * q], kb, 8);
-                    s[8 + q] = id | ((len - 1u) << 20);
-                    std::memcpy(&s[12 + q], kb + 8, 4);
-                    break;
-                }
-                eb = eb + 1u == enb ? 0u : eb + 1u;
-            }
-        }
-    }
+    const bool pm16 = max_len <= 16;      // the matcher instantiations for max_len <= 16 read 16-bit prefix-table entries
+    const size_t total_key_bytes = (size_t)key_offsets[n_keys];
+    int rc;
+    if ((rc = ensure(c, c->buckets, nbuckets * 16))) return rc;
+    if ((rc = ensure(c, c->keys, key_plane * (size_t)nw * 8))) return rc;
+    if ((rc = ensure(c, c->ebk, (size_t)enb * 64))) return rc;
+    if ((rc = ensure(c, c->byte_id, 256 * 4))) return rc;
+    if ((rc = ensure(c, c->direct2, 65536 * 4))) return rc;
+    if ((rc = ensure(c, c->bloom, SAGE_BLOOM_BITS / 8))) return rc;
+    if ((rc = ensure(c, c->pmask, (size_t)SAGE_PMASK_SLOTS * 4))) return rc;
+    if ((rc = ensure(c, c->pmask8, (size_t)SAGE_PMASK8_SLOTS * 4))) return rc;
+    if ((rc = ensure(c, c->vk_bytes, total_key_bytes + 16))) return rc;
+    if ((rc = ensure(c, c->vk_off, (size_t)(n_keys + 1) * 8))) return rc;
+    if (key_ids && (rc = ensure(c, c->vk_ids, (size_t)n_keys * 4))) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->vk_bytes.p, key_bytes, total_key_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->vk_off.p, key_offsets, (size_t)(n_keys + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    if (key_ids) HIP_TRY(c, hipMemcpyAsync(c->vk_ids.p, key_ids, (size_t)n_keys * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->buckets.p, 0xFF, nbuckets * 16, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->ebk.p, 0xFF, (size_t)enb * 64, c->stream));      // meta words = SAGE_SLOT_EMPTY
+    HIP_TRY(c, hipMemsetAsync(c->keys.p, 0, key_plane * (size_t)nw * 8, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->byte_id.p, 0xFF, 256 * 4, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->direct2.p, 0xFF, 65536 * 4, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->bloom.p, 0, SAGE_BLOOM_BITS / 8, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->pmask.p, 0, (size_t)SAGE_PMASK_SLOTS * 4, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->pmask8.p, 0, (size_t)SAGE_PMASK8_SLOTS * 4, c->stream));
+    VocabBuild vb{c->vk_bytes.as<uint8_t>(), c->vk_off.as<int64_t>(), key_ids ? c->vk_ids.as<int32_t>() : nullptr, (uint32_t)n_keys,
+                  (uint32_t)max_len, nw, c->buckets.as<uint32_t>(), bmask, c->keys.as<uint64_t>(), (uint32_t)key_plane,
+                  c->byte_id.as<uint32_t>(), c->direct2.as<uint32_t>(), c->bloom.as<uint32_t>(), c->pmask.as<uint32_t>(),
+                  c->pmask8.as<uint32_t>(), pm16 ? 1 : 0, c->ebk.as<uint32_t>(), enb};
+    k_vocab_build<<<cdiv((uint64_t)n_keys, 256), 256, 0, c->stream>>>(vb);
+    HIP_TRY(c, hipGetLastError());
+    uint32_t byte_id[256];
+    HIP_TRY(c, hipMemcpyAsync(byte_id, c->byte_id.p, sizeof byte_id, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (int b = 0; b < 256; ++b)
         if (byte_id[b] == SAGE_SLOT_EMPTY) {
+            c->have_vocab = false;
             char msg[64];
             std::snprintf(msg, sizeof msg, "missing byte 0x%02x", b);
             return fail(c, SAGE_E_MISSING_BYTE, msg);
         }
-    int rc;
-    if ((rc = ensure(c, c->buckets, slots.size() * 4))) return rc;
-    if ((rc = ensure(c, c->keys, keys.size() * 8))) return rc;
-    if ((rc = ensure(c, c->ebk, etab.size() * 4))) return rc;
-    if ((rc = ensure(c, c->byte_id, 256 * 4))) return rc;
-    if ((rc = ensure(c, c->direct2, direct2.size() * 4))) return rc;
-    if ((rc = ensure(c, c->bloom, bloom.size() * 4))) return rc;
-    if ((rc = ensure(c, c->pmask, pmask.size() * 4))) return rc;
-    if ((rc = ensure(c, c->pmask8, pmask8.size() * 4))) return rc;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(c->buckets.p, slots.data(), slots.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->keys.p, keys.data(), keys.size() * 8, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->ebk.p, etab.data(), etab.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->byte_id.p, byte_id.data(), 256 * 4, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->direct2.p, direct2.data(), direct2.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->bloom.p, bloom.data(), bloom.size() * 4, hipMemcpyHostToDevice));
-    if (max_len <= 16) {   // the matcher instantiations for max_len <= 16 read 16-bit entries
-        std::vector<uint16_t> a(pmask.begin(), pmask.end()), b(pmask8.begin(), pmask8.end());
-        HIP_TRY(c, hipMemcpy(c->pmask.p, a.data(), a.size() * 2, hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(c->pmask8.p, b.data(), b.size() * 2, hipMemcpyHostToDevice));
-    } else {
-        HIP_TRY(c, hipMemcpy(c->pmask.p, pmask.data(), pmask.size() * 4, hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(c->pmask8.p, pmask8.data(), pmask8.size() * 4, hipMemcpyHostToDevice));
-    }
     c->bucket_mask = bmask;
     c->enb = enb;
     c->key_plane = (uint32_t)key_plane;

@@ -138,6 +138,65 @@ __global__ __launch_bounds__(256) void k_match(const uint8_t* __restrict__ corpu
 }
 
 // ----------------------------------------------------------------------------------------------------------
+// K0  vocabulary tables, built on the GPU from the packed keys (model.py:28-51 keeps a dict; this is its device form).
+// One thread per key: key planes, single-byte and 2-byte direct tables, the LDS filter's bits, the two prefix-length
+// tables, the slot table (plain / column-probe matchers) and the embedded-key table (queued matcher).  Slots are
+// claimed with compare-and-swap in slot order, so "last slot empty" still means "nothing spilled to the next bucket";
+// which key sits in which slot depends on the run, what a lookup returns does not (keys are unique).
+// ----------------------------------------------------------------------------------------------------------
+struct VocabBuild {
+    const uint8_t* key_bytes; const int64_t* key_off; const int32_t* key_ids; uint32_t n_keys; uint32_t max_len; int nw;
+    uint32_t* slots; uint32_t bucket_mask; uint64_t* keys; uint32_t key_plane;
+    uint32_t* byte_id; uint32_t* direct2; uint32_t* bloom; uint32_t* pmask; uint32_t* pmask8; int pm16;
+    uint32_t* etab; uint32_t enb;
+};
+__device__ __forceinline__ void pmask_or(uint32_t* tab, uint32_t idx, uint32_t bits, int pm16) {
+    if (pm16) atomicOr(&tab[idx >> 1], (bits & 0xFFFFu) << ((idx & 1u) * 16u));
+    else atomicOr(&tab[idx], bits);
+}
+__global__ __launch_bounds__(256) void k_vocab_build(VocabBuild B) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= B.n_keys) return;
+    const uint32_t id = B.key_ids ? (uint32_t)B.key_ids[i] : i;
+    const uint8_t* k = B.key_bytes + B.key_off[i];
+    const uint32_t len = (uint32_t)(B.key_off[i + 1] - B.key_off[i]);
+    if (len > B.max_len) return;      // can never match (model.py:90 tries lengths max_len..1 only): in no table
+    uint64_t words[4] = {0ull, 0ull, 0ull, 0ull};
+    for (uint32_t j = 0; j < len; ++j) words[j >> 3] |= (uint64_t)k[j] << (8u * (j & 7u));
+    for (int w = 0; w < B.nw; ++w) B.keys[(size_t)w * B.key_plane + id] = words[w];
+    if (len == 1u) { B.byte_id[k[0]] = id; return; }
+    if (len == 2u) B.direct2[(uint32_t)k[0] | ((uint32_t)k[1] << 8)] = id;     // (and in the slot table for k_match)
+    uint32_t h = SAGE_FNV_OFFSET;
+    for (uint32_t j = 0; j < len; ++j) {
+        h = sage_fnv_step(h, k[j]);
+        if (j == 3u) pmask_or(B.pmask, sage_mix32(h) & (SAGE_PMASK_SLOTS - 1u), 1u << (len - 1u), B.pm16);    // len >= 4 here
+        if (j == 7u) pmask_or(B.pmask8, sage_mix32(h) & (SAGE_PMASK8_SLOTS - 1u), 1u << (len - 1u), B.pm16);  // len >= 8 here
+    }
+    const uint32_t f = sage_mix32(h);
+    atomicOr(&B.bloom[sage_bloom_word(f)], sage_bloom_mask(f));
+    {
+        const uint32_t slot = sage_slot_make(id, len, f);
+        uint32_t b = f & B.bucket_mask;
+        for (bool done = false; !done; b = (b + 1u) & B.bucket_mask)
+            for (int q = 0; q < 4 && !done; ++q) done = atomicCAS(&B.slots[(size_t)b * 4 + q], SAGE_SLOT_EMPTY, slot) == SAGE_SLOT_EMPTY;
+    }
+    if (len >= 3u) {
+        const uint32_t meta = id | ((len - 1u) << 20);
+        uint32_t b = __umulhi(f, B.enb);
+        for (bool done = false; !done; b = b + 1u == B.enb ? 0u : b + 1u) {
+            uint32_t* s = B.etab + (size_t)b * 16;
+            for (int q = 0; q < 4 && !done; ++q)
+                if (atomicCAS(&s[8 + q], SAGE_SLOT_EMPTY, meta) == SAGE_SLOT_EMPTY) {
+                    s[2 * q] = (uint32_t)words[0];
+                    s[2 * q + 1] = (uint32_t)(words[0] >> 32);
+                    s[12 + q] = (uint32_t)words[1];
+                    done = true;
+                }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------
 // K1 (filtered form): the same match, with a 128 KiB presence filter (2 bits per key) resident in LDS.  k_match is
 // bound by the L2 request rate of its 15 bucket probes per byte (measured: ~20 L2 requests per byte); the filter
 // turns most misses into two LDS reads (measured: ~5 L2 requests per byte).  Candidate lengths are probed in chunks
