@@ -290,8 +290,16 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
                 uint32_t hdr = SAGE_DH_VALID | (w.never ? SAGE_DH_NEVER : 0u) | (w.pl << 24) | (w.pr << 26);
                 if (!LONG) {
                     my[0] = hdr | w.k | (w.m << 12);
-                    if (bitmap)      // independent loads of a 32 KB table, after the walk (not on its dependent chain)
-                        for (uint32_t j = 0; j < L; ++j) { const uint32_t id = my[1 + j]; bad = bad || ((bitmap[id >> 5] >> (id & 31u)) & 1u); }
+                    if (bitmap) {    // independent loads of a 32 KB table, after the walk and all in flight together
+                        uint32_t acc = 0;
+#pragma unroll
+                        for (uint32_t j = 0; j < SAGE_DESC_MAXWIN; ++j) {
+                            const uint32_t id = my[1 + j];
+                            const uint32_t bits = bitmap[j < L ? id >> 5 : 0u];       // (slots past L hold stale words)
+                            acc |= j < L ? bits >> (id & 31u) : 0u;
+                        }
+                        bad = (acc & 1u) != 0u;
+                    }
                 } else {
                     uint32_t at = atomicAdd(D.pool_cursor, L);
                     const bool fits = at + L <= D.pool_cap && at + L >= at;
