@@ -145,7 +145,7 @@ def test_fast_sage_lines_golden(tag):
 
 
 @pytest.mark.parametrize("style,max_len,dim", [("en", 16, 50), ("tr", 17, 50), ("en", 16, 300), ("en", 24, 20), ("en", 8, 50),
-                                               ("en", 32, 64)])
+                                               ("en", 32, 64), ("en", 12, 50), ("tr", 20, 32), ("en", 5, 50)])
 def test_step_vs_oracle(style, max_len, dim):
     from oracle import sage_oracle as orc
     from sage_amd import synth
@@ -238,6 +238,52 @@ def test_long_windows_vs_oracle():
     eng.set_corpus(flat, off)
     eng.set_embeddings(emb)
     _check_step(eng, segment_line_bounds(len(lines), 1, flush=9), tt, ttr, losses, sizes, want_occ=occs)
+    eng.close()
+
+
+def test_dense_candidates_vs_oracle():
+    """Text in which EVERY position has a key of every length (runs of one letter, all of whose powers are keys): a
+    64-byte tile then holds 64 x 8 candidates in the long class and 64 x 4 in the middle one, more than the matcher's
+    candidate queue takes at once (224), so the queue is worked in windows; all three matchers must agree with the
+    oracle, and so must the step (ablations that re-tokenize a whole run)."""
+    from oracle import sage_oracle as orc
+    from sage_amd import synth
+    from sage_amd.parallel import pack_lines, segment_line_bounds
+    vocab = [bytes([i]) for i in range(256)]
+    for ch in (b"a", b"b"):
+        vocab += [ch * j for j in range(2, 17)]
+    vocab += [b"ab" * j for j in range(1, 9)] + [b"aab", b"abb", b"ba", b"bab", b" a", b"a ", b"aaaa bbbb"]
+    rs = np.random.RandomState(5)
+    lines = []
+    for i in range(40):
+        parts = []
+        for _ in range(rs.randint(3, 9)):
+            kind = rs.randint(0, 4)
+            n = int(rs.randint(1, 70))
+            parts.append((b"a" * n, b"b" * n, b"ab" * (n // 2 + 1), b" ")[kind])
+        lines.append(b"".join(parts) + b"\n")
+    lines.append(b"a" * 700 + b"\n")
+    emb = synth.make_embeddings(len(vocab), 50, seed=4)
+    tok = orc.OracleTokenizer(vocab, 16)
+    eng = _engine()
+    eng.set_vocab(vocab, None, 16)
+    flat, off = pack_lines(lines)
+    eng.set_corpus(flat, off)
+    want_ids = []
+    for ln in lines:
+        want_ids += [t for t, _, _ in tok.tokenize(ln)]
+    got = {}
+    for mode in (0, 1, 2):
+        eng.set_match_mode(mode)
+        got[mode] = eng.tokenize(0, len(lines))[0].tolist()
+    eng.set_match_mode(0)
+    assert got[0] == got[1] == got[2]
+    assert got[0] == want_ids
+    occs = {}
+    losses, tt, ttr, sizes = orc.run_shard(tok, lines, emb, flush=13, occurrences=occs)
+    assert tt == len(got[0])
+    eng.set_embeddings(emb)
+    _check_step(eng, segment_line_bounds(len(lines), 1, flush=13), tt, ttr, losses, sizes, want_occ=occs)
     eng.close()
 
 
