@@ -222,7 +222,8 @@ __device__ __forceinline__ uint32_t window_pairs(uint32_t pl_, uint32_t c_, uint
 // ----------------------------------------------------------------------------------------------------------
 struct DescribeArgs {
     uint4* desc;
-    uint32_t* occ_a;              // [n_occ] ablated id | (touches an inexact row) << 31
+    uint32_t* occ_a;              // [n_occ] ablated id | pl << 20 | pr << 22 | min(m, 127) << 24 | (touches an inexact row) << 31:
+                                  // all k_logsig needs of an occurrence (m = 127: look at the descriptor)
     uint32_t* npairs_ab;          // [n_occ] position pairs of the ablated window (-> offsets of its dots)
     uint32_t* npairs_all;         // [n_occ] ablated + base position pairs; 0 for a giant
     uint32_t* giant_list; uint32_t* giant_count;
@@ -238,6 +239,7 @@ struct DescribeArgs {
     uint32_t* inex_list; uint32_t* inex_count;
 };
 #define SAGE_OCC_INEXACT 0x80000000u
+#define SAGE_OCC_M_SEE_DESC 127u
 
 template <bool LONG>
 __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* __restrict__ occ_tok, uint32_t n_occ,
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
                 n_rows += L + w.m;
                 n_wrows += L;
                 n_ab += ab_pairs;
-                D.occ_a[o] = w.a | (bad ? SAGE_OCC_INEXACT : 0u);
+                D.occ_a[o] = w.a | (w.pl << 20) | (w.pr << 22) | (min(w.m, SAGE_OCC_M_SEE_DESC) << 24) | (bad ? SAGE_OCC_INEXACT : 0u);
                 D.npairs_ab[o] = ab_pairs;
                 const bool giant = LONG && my_pairs > (unsigned long long)SAGE_PART_GIANT;
                 D.npairs_all[o] = giant ? 0u : (uint32_t)my_pairs;
@@ -722,13 +724,16 @@ __global__ __launch_bounds__(256) void k_logsig(const uint4* __restrict__ desc, 
         if (DET) osum1[threadIdx.x] = 0ull;
         // phase-2 operands are independent of phase 1: issue their loads first
         const uint32_t o = o0 + threadIdx.x;
-        uint4 h = make_uint4(0, 0, 0, 0);
-        uint32_t t = 0;
-        if (threadIdx.x < nt) { h = desc[(size_t)o * 4]; t = occ_tok[o]; }
+        uint32_t t = 0, a_w0 = 0;
+        if (threadIdx.x < nt) { a_w0 = occ_a[o]; t = occ_tok[o]; }
         __syncthreads();
         // ---- loads of both phases issued together: the pair-cache window of this thread's occurrence (phase 2), the
         // ablated id, and the first LOGSIG_PF dots of this thread's slice (phase 1) -- one exposed latency per tile
-        const Win w = win_decode(h.x, h.z, h.w);
+        // pads and base-span length ride in the ablated-id word: the 64-byte descriptor is read only for a span of
+        // 127 tokens or more (a strided 16-byte read per occurrence otherwise: 4x its bytes in lines)
+        Win w;
+        w.pl = (a_w0 >> 20) & 3u; w.pr = (a_w0 >> 22) & 3u; w.m = (a_w0 >> 24) & 127u; w.k = 0; w.L = 0; w.pooled = false;
+        if (w.m == SAGE_OCC_M_SEE_DESC) { const uint4 h = desc[(size_t)o * 4]; w = win_decode(h.x, h.z, h.w); }
         // base window: pair (i,i+1) counts iff i or i+1 is in the centre [t, t+m): rel = i-t in [-1, m-1] clipped to
         // the window [t-pl, t+m+pr-1]; pair (i,i+2) iff rel in [0,m-1] or rel+2 in [0,m-1] (not contiguous for
         // m == 1: rel = -1 joins two pads).
@@ -738,9 +743,7 @@ __global__ __launch_bounds__(256) void k_logsig(const uint4* __restrict__ desc, 
         const bool live = threadIdx.x < nt;
         const bool small = im <= LOGSIG_WIN - 2;     // rel in [-2, LOGSIG_WIN - 3] covers every term
         double2 W[LOGSIG_WIN];
-        uint32_t a_w0 = 0;
         if (live) {
-            a_w0 = occ_a[o];
             if (small) {
 #pragma unroll
                 for (int q = 0; q < LOGSIG_WIN; ++q) {
