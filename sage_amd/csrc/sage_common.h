@@ -93,7 +93,6 @@ SAGE_HD uint32_t sage_key_hash_b(uint64_t k) {
 #define SAGE_DH_NEVER 0x20000000u
 #define SAGE_DH_GIANT 0x10000000u   // more than SAGE_PART_GIANT position pairs: the distinct count's slow path
 #define SAGE_DH_K(h) ((h) & 0xFFFu)
-#define SAGE_DH_M(h) (((h) >> 12) & 0x7FFu)   // inline descriptors only: m <= SAGE_INLINE_MAX_M
-#define SAGE_DH_BASEIN 0x00800000u  // inline: words 15, 14, ... hold the base window [pads | span | pads] (it fitted behind the ablated window)
+#define SAGE_DH_M(h) (((h) >> 12) & 0xFFFu)
 #define SAGE_DH_PL(h) (((h) >> 24) & 3u)
 #define SAGE_DH_PR(h) (((h) >> 26) & 3u)

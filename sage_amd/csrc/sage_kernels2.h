@@ -135,9 +135,8 @@ struct Ablation {
 };
 
 // ldx(p) returns M[p].x; the kernels pass a loader that serves a staged span from LDS.
-// base(id) receives the base window (left pads, the tokens of the base span, right pads) in order.
-template <class LoadX, class Emit, class Base>
-__device__ __forceinline__ Ablation walk_occurrence(const WalkArrays& A, uint32_t t, uint32_t p0, LoadX&& ldx, Emit&& emit, Base&& base) {
+template <class LoadX, class Emit>
+__device__ __forceinline__ Ablation walk_occurrence(const WalkArrays& A, uint32_t t, uint32_t p0, LoadX&& ldx, Emit&& emit) {
     Ablation r;
     const uint32_t w0 = A.tok_w0[t];
     const uint2 m0 = A.M[p0];
@@ -145,9 +144,8 @@ __device__ __forceinline__ Ablation walk_occurrence(const WalkArrays& A, uint32_
     const uint32_t loc3 = SAGE_T_LOC3(w0);
     r.pl = loc3 < 2u ? loc3 : 2u;                              // padleft = min(pad, loc), model.py:218
     r.k = 0; r.m = 1; r.pr = 0; r.never = false; r.complete = false;
-    if (r.pl == 2u) { const uint32_t id = SAGE_T_ID(A.tok_w0[t - 2]); base(id); if (!emit(id)) return r; }
-    if (r.pl >= 1u) { const uint32_t id = SAGE_T_ID(A.tok_w0[t - 1]); base(id); if (!emit(id)) return r; }
-    base(r.a);
+    if (r.pl == 2u && !emit(SAGE_T_ID(A.tok_w0[t - 2]))) return r;
+    if (r.pl >= 1u && !emit(SAGE_T_ID(A.tok_w0[t - 1]))) return r;
     // first piece: longest key of at most width-1 bytes = the second-longest match
     if (!emit(SAGE_M_ID(m0.y))) return r;
     r.k = 1;
@@ -163,7 +161,6 @@ __device__ __forceinline__ Ablation walk_occurrence(const WalkArrays& A, uint32_
         q += SAGE_M_LEN(mq);
         while (bcur < q) {                                     // on_base: is q a base-token start? (model.py:163-165,200)
             const uint32_t mb = ldx(bcur);
-            base(SAGE_M_ID(mb));
             blast = SAGE_M_ENDS(mb) != 0u;
             bcur += SAGE_M_LEN(mb); ++r.m;
         }
@@ -171,31 +168,22 @@ __device__ __forceinline__ Ablation walk_occurrence(const WalkArrays& A, uint32_
     }
     if (rejoined) {
         const uint32_t m1 = ldx(q);
-        base(SAGE_M_ID(m1));
         if (!emit(SAGE_M_ID(m1))) return r;
         if (SAGE_M_ENDS(m1)) {
             r.pr = 1;                                          // padright = min(pad, ntok - beyond)
         } else {
             r.pr = 2;
-            const uint32_t id = SAGE_M_ID(ldx(q + SAGE_M_LEN(m1)));
-            base(id);
-            if (!emit(id)) return r;
+            if (!emit(SAGE_M_ID(ldx(q + SAGE_M_LEN(m1))))) return r;
         }
     } else {
         while (!blast) {                                       // base span runs to the end of the line
             const uint32_t mb = ldx(bcur);
-            base(SAGE_M_ID(mb));
             blast = SAGE_M_ENDS(mb) != 0u;
             bcur += SAGE_M_LEN(mb); ++r.m;
         }
     }
     r.complete = true;
     return r;
-}
-
-template <class LoadX, class Emit>
-__device__ __forceinline__ Ablation walk_occurrence(const WalkArrays& A, uint32_t t, uint32_t p0, LoadX&& ldx, Emit&& emit) {
-    return walk_occurrence(A, t, p0, ldx, emit, [](uint32_t) {});
 }
 
 // Position pairs at distance 1 or 2 of a window [pl pads | c centre elements | pr pads] with at least one end in
@@ -282,25 +270,16 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
         const uint32_t p0 = live ? A.occ_pos[o] : 0u;
         const uint32_t seg = live ? find_segment(S, t) : 0xFFFFFFFFu;
         unsigned long long my_pairs = 0;
-        bool is_long = false, done = false, bad = false, basefit = !LONG;
+        bool is_long = false, done = false, bad = false;
         if (live) {
             uint32_t L = 0;
             Ablation w;
             if (!LONG) {
-                // the ablated window fills words 1.. upwards, the base window words 15.. downwards for as long as the two
-                // do not meet (the usual case: 7 + 5 ids): the distinct count then needs nothing but the descriptor
-                uint32_t nbase = 0;
                 w = walk_occurrence(A, t, p0, ldx, [&](uint32_t id) {
                     if (L == SAGE_DESC_MAXWIN) return false;     // does not fit: leave it to the long pass
-                    if (1u + L > 15u - nbase) basefit = false;
                     my[1 + L] = id;
                     ++L;
                     return true;
-                }, [&](uint32_t id) {
-                    if (!basefit) return;
-                    if (15u - nbase <= L) { basefit = false; return; }
-                    my[15u - nbase] = id;
-                    ++nbase;
                 });
                 is_long = !w.complete || w.m > SAGE_INLINE_MAX_M;
             } else {
@@ -312,7 +291,7 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
                 done = true;
                 uint32_t hdr = SAGE_DH_VALID | (w.never ? SAGE_DH_NEVER : 0u) | (w.pl << 24) | (w.pr << 26);
                 if (!LONG) {
-                    my[0] = hdr | w.k | (w.m << 12) | (basefit ? SAGE_DH_BASEIN : 0u);
+                    my[0] = hdr | w.k | (w.m << 12);
                     if (bitmap) {    // independent loads of a 32 KB table, after the walk and all in flight together
                         uint32_t acc = 0;
 #pragma unroll

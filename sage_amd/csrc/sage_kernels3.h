@@ -104,22 +104,12 @@ __device__ __forceinline__ void load_desc(const uint4* __restrict__ desc, uint32
 __device__ __forceinline__ void load_inline(const uint4* __restrict__ desc, const uint32_t* __restrict__ occ_tok,
                                             const uint32_t* __restrict__ tok_w0, uint32_t o, InlineOcc& x) {
     load_desc(desc, o, x.d);
-    const uint32_t h = x.d[0];
-    const uint32_t pl = SAGE_DH_PL(h);
-    const uint32_t nb = (h & SAGE_DH_OVER) ? 0u : pl + SAGE_DH_M(h) + SAGE_DH_PR(h);
-    if ((h & SAGE_DH_BASEIN) && !(h & SAGE_DH_OVER)) {
-        // the base window rides in the descriptor's tail (k_describe): no token loads, and the token index only for a
-        // base window of more than BASE_PF ids
-#pragma unroll
-        for (int i = 0; i < BASE_PF; ++i) x.base[i] = (uint32_t)i < nb ? x.d[15 - i] : 0u;
-        x.t = nb > (uint32_t)BASE_PF ? occ_tok[o] : 0u;
-        x.a = pl == 0u ? x.base[0] : (pl == 1u ? x.base[1] : x.base[2]);
-        return;
-    }
     x.t = occ_tok[o];
+    const uint32_t pl = SAGE_DH_PL(x.d[0]);
+    const uint32_t nb = (x.d[0] & SAGE_DH_OVER) ? 0u : pl + SAGE_DH_M(x.d[0]) + SAGE_DH_PR(x.d[0]);
 #pragma unroll
     for (int i = 0; i < BASE_PF; ++i) x.base[i] = (uint32_t)i < nb ? SAGE_T_ID(tok_w0[x.t - pl + (uint32_t)i]) : 0u;
-    x.a = (h & SAGE_DH_OVER) ? SAGE_T_ID(tok_w0[x.t]) : x.base[pl < (uint32_t)BASE_PF ? pl : 0];
+    x.a = (x.d[0] & SAGE_DH_OVER) ? SAGE_T_ID(tok_w0[x.t]) : x.base[pl < (uint32_t)BASE_PF ? pl : 0];
     if (pl >= (uint32_t)BASE_PF) x.a = SAGE_T_ID(tok_w0[x.t]);
 }
 
