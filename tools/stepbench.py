@@ -1,0 +1,23 @@
+"""Per-kernel times of the ablation step on 300k lines of the bench corpus (quick A/B runs; SAGE_LIB=path picks another build)."""
+import os, pathlib, sys, numpy as np
+sys.path.insert(0, '/root/repo')
+from sage_amd import _lib, synth
+from sage_amd._lib import HipSage
+from sage_amd.parallel import segment_line_bounds
+if os.environ.get('SAGE_LIB'): _lib.LIB_PATH = pathlib.Path(os.environ['SAGE_LIB'])
+N = int(os.environ.get('SB_LINES', '300000'))
+seed = synth.DEFAULT_SEED
+head, ho = synth.make_corpus(14000, seed=seed, style="en", n_types=1_000_000)
+vocab = synth.make_vocab(head, ho, 262144, 16, sample_bytes=6_000_000)
+corpus, off = synth.make_corpus(N, seed=seed, style="en", n_types=1_000_000)
+e = HipSage(0); e.set_vocab(vocab, None, 16); e.set_corpus(corpus, off)
+counts = np.bincount(e.tokenize(0, N)[0], minlength=len(vocab))
+emb = synth.make_embeddings(len(vocab), 50, seed=seed, unseen=~(counts > 0))
+e.set_embeddings(emb)
+b = segment_line_bounds(N, 4)
+r = e.ablation_step(b)
+e.set_profiling(True); e.reset_kernel_times()
+R = 3
+for _ in range(R): r = e.ablation_step(b)
+kt = e.kernel_times()
+print("tokens", r[2], "triples", r[3], {k: round(v[0] / R, 3) for k, v in kt.items() if v[0] > 0}, "sum", round(sum(v[0] for v in kt.values()) / R, 2), flush=True)
