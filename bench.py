@@ -38,10 +38,10 @@ sys.path.insert(0, str(REPO))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # kernel class (sage_hip.h SAGE_K_*) -> the kernel that dominates it in the rocprofv3 traces under profiles/
-CLASS_KERNEL = {"match": "k_match_lds", "score": "k_dots", "count": "k_key_dedupe", "partition": "k_key_partition<1>",
+CLASS_KERNEL = {"match": "k_match_lds", "score": "k_dots", "count": "k_key_dedupe", "partition": "k_key_partition3",
                 "describe": "k_describe<false>", "pairs": "k_pair_cache", "logsig": "k_logsig", "walk": "k_walk_write"}
 # what bounds each kernel class (Kernels): only the "hbm" ones stream HBM; the HBM peak is quoted for all
-CLASS_BOUND = {"match": "valu-issue", "score": "l2-fabric-gather", "pairs": "l2-fabric-gather", "fix": "l2-fabric-gather",
+CLASS_BOUND = {"match": "vl1d-requests", "score": "l2-fabric-gather", "pairs": "l2-fabric-gather", "fix": "l2-fabric-gather",
                "count": "hbm", "partition": "hbm", "describe": "lds-latency", "logsig": "hbm", "walk": "latency"}
 
 
@@ -309,7 +309,7 @@ def main():
                          "algorithmic_bytes_per_launch": per_kernel_bytes[dom] / launches_per_step,
                          "elem_bytes": eb,
                          "note": "peak is HBM's 8 TB/s for every kernel; kernels whose bound is not 'hbm' are limited elsewhere "
-                                 "(score/pairs gather rows that live in L2 / Infinity Cache, match is VALU-issue bound): DESIGN.md, Kernels"},
+                                 "(score/pairs gather rows that live in L2 / Infinity Cache, match is bound by the vector L1's request handling: random table probes, TA busy 75 %): DESIGN.md, Kernels"},
             "step_roofline": {"measured_hbm_bytes_per_step": pmc_traffic("__step_total__", args) if world == 1 else None,
                               "bytes_per_token_A": A_of(eb), "achieved_GBs_per_gpu": step_gbs(eb), "frac": step_gbs(eb) / HBM_PEAK_GBS,
                               "bytes_per_token_A_e8": A_of(8), "frac_e8": step_gbs(8) / HBM_PEAK_GBS,

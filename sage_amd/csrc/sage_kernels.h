@@ -572,7 +572,7 @@ __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ 
             for (int i = 0; i < 2 * NW; ++i) T[i] = __funnelshift_r(d[i], d[i + 1], sh);
         }
         const uint32_t lim = min(rm, (uint32_t)v.max_len);
-        const uint32_t d2 = v.direct2[T[0] & 0xFFFFu];
+        uint32_t d2 = SAGE_SLOT_EMPTY;
         uint32_t fh[ML + 1];
         uint32_t miss = 0;   // bit (j-1) set when the filter rules length j out
         using PM = typename std::conditional<(NW <= 2), uint16_t, uint32_t>::type;
@@ -585,13 +585,19 @@ __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ 
             h = sage_fnv_step(h, b);
             const uint32_t f = sage_mix32(h);
             if (j == 4) pm = reinterpret_cast<const PM*>(v.pmask)[f & (SAGE_PMASK_SLOTS - 1u)];   // issued early, used last
-            if (j == 8 && ML > 8) pm8 = reinterpret_cast<const PM*>(v.pmask8)[f & (SAGE_PMASK8_SLOTS - 1u)] | 0x7Fu;
             fh[j] = f;
             const uint32_t mk = sage_bloom_mask(f);
             const uint32_t lack = (bloom[sage_bloom_word(f)] & mk) ^ mk;      // 0 when both bits are present
             miss |= min(lack, 1u) << (j - 1);
         }
         // candidate lengths: pass the filter, 2 <= j <= lim
+        // Requests to the vector L1 are what this kernel is short of, so the two lookups that most lanes can do without are
+        // made late and only by the lanes that need them (-5 %): the 8-byte prefix table by lanes that still have a
+        // candidate of 8+ bytes, the 2-byte table (below) by lanes with fewer than two longer matches.
+        if (ML > 8) {
+            const uint32_t c0 = ~miss & (pm | 0x6u) & ((lim >= 32u ? 0xFFFFFFFFu : ((1u << lim) - 1u)) & ~1u) & (ML >= 32 ? 0xFFFFFFFFu : ((1u << ML) - 1u));
+            if (c0 >> 7) pm8 = reinterpret_cast<const PM*>(v.pmask8)[fh[8] & (SAGE_PMASK8_SLOTS - 1u)] | 0x7Fu;
+        }
         const uint32_t cand = ~miss & (pm | 0x6u) & pm8 & ((lim >= 32u ? 0xFFFFFFFFu : ((1u << lim) - 1u)) & ~1u) & (ML >= 32 ? 0xFFFFFFFFu : ((1u << ML) - 1u));
         uint64_t W[NW];
 #pragma unroll
@@ -602,10 +608,13 @@ __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ 
         if constexpr (QUEUED) {
             uint2* q = mq_all + (tid >> 6) * MQ_CAP;
             if constexpr (ML >= 9) {
-                if (__any((cand >> 8) != 0u)) probe_queued<NW, 9, ML, ML>(v, cand, fh, W, top, q, lane);
+                // (finer classes = more chances to stop early = fewer requests, up to a point: 13+, 9..12, 7..8, 5..6, 3..4
+                // measures 6.53 ms per 152 MB, 9+, 5..8, 3..4 6.77, one class per length 7.07)
+                if constexpr (ML >= 13) { if (__any((cand >> 12) != 0u)) probe_queued<NW, 13, ML, ML>(v, cand, fh, W, top, q, lane); }
+                if (__any(((cand >> 8) & 0xFu) != 0u)) probe_queued<NW, 9, (ML < 12 ? ML : 12), ML>(v, cand, fh, W, top, q, lane);
             }
-            // (one class 3..8 saves a round trip but loses the early stop between 5..8 and 3..4: 7.56 vs 7.03 ms per 152 MB)
-            probe_queued<NW, 5, 8, ML>(v, cand, fh, W, top, q, lane);
+            probe_queued<NW, 7, 8, ML>(v, cand, fh, W, top, q, lane);
+            probe_queued<NW, 5, 6, ML>(v, cand, fh, W, top, q, lane);
             probe_queued<NW, 3, 4, ML>(v, cand, fh, W, top, q, lane);
         } else {
             if constexpr (ML >= 9) probe_sparse<NW, 9, ML, ML>(v, cand, fh, W, top);
@@ -614,10 +623,11 @@ __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ 
             const uint32_t c2 = top.m2 == 0u ? cand : 0u;
             if (__any((c2 & 0x0Cu) != 0u)) probe_chunk<NW, 3, 4, ML>(v, c2, fh, W, top);
         }
-        // 2-byte keys need no hash: a 256 KiB table indexed by the two bytes (load issued at the top of the tile)
+        // 2-byte keys need no hash: a 256 KiB table indexed by the two bytes
+        if (top.m2 == 0u && lim >= 2u) d2 = v.direct2[T[0] & 0xFFFFu];
         top.fold((lim >= 2u && d2 != SAGE_SLOT_EMPTY) ? (d2 | (2u << 20)) : 0u);
         // the single byte always matches: it is the longest match when nothing else hit, the second when one did
-        top.fold(v.byte_id[T[0] & 0xFFu] | (1u << 20));
+        if (top.m2 == 0u) top.fold(v.byte_id[T[0] & 0xFFu] | (1u << 20));
         // (more than two matches may have been folded in -- a chunk probes all its lengths -- m1 and m2 are the two
         // longest of them in any case; with a single match m2 is 0 = "no second match", len2 == 0 iff len1 == 1)
         // streamed once: keep it out of the way of the table and key planes in L2
