@@ -83,7 +83,7 @@ int sage_tokenize(sage_ctx* ctx, int64_t line_begin, int64_t line_end, int32_t* 
  * allocate device memory at the point of the call -- code under HIP graph capture, tight serving loops that tokenize
  * request batches with the resident vocabulary, harnesses that forbid hipMalloc.  The call allocates and frees no
  * device memory: its scratch (text copy with its zero pad, line remainders, the match table, per-line counters)
- * lives in a static device array of ~11.6 MiB that every GPU the library runs on holds until the process ends.
+ * lives in a static device array of ~10.6 MiB that every GPU the library runs on holds until the process ends.
  * Inputs and outputs are the CALLER's DEVICE buffers: d_text[n_bytes] holds the lines back to back, d_line_offsets
  * [n_lines + 1] their byte offsets (int64, from 0 to n_bytes); d_ids/d_starts/d_widths[capacity] (all three or none)
  * and d_counts[n_lines] (optional) receive what sage_tokenize returns; *out_total (host) = number of tokens.  The

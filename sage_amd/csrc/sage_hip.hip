@@ -43,15 +43,14 @@ constexpr size_t na_up(size_t x) { return (x + NA_ALIGN - 1) / NA_ALIGN * NA_ALI
 constexpr size_t NA_TEXT = 0;                                                          // text + 1 KiB zero pad
 constexpr size_t NA_REM = NA_TEXT + na_up(SAGE_NOALLOC_MAX_BYTES + 1024);              // bytes to the line end
 constexpr size_t NA_M = NA_REM + na_up(SAGE_NOALLOC_MAX_BYTES + 1024);                 // match table, 8 B per byte
-constexpr size_t NA_LEN = NA_M + na_up((size_t)SAGE_NOALLOC_MAX_BYTES * 8);            // length plane, 1 B per byte
-constexpr size_t NA_NTOK = NA_LEN + na_up(SAGE_NOALLOC_MAX_BYTES + 64);
+constexpr size_t NA_NTOK = NA_M + na_up((size_t)SAGE_NOALLOC_MAX_BYTES * 8);
 constexpr size_t NA_NOCC = NA_NTOK + na_up((size_t)SAGE_NOALLOC_MAX_LINES * 4);
 constexpr size_t NA_TOKOFF = NA_NOCC + na_up((size_t)SAGE_NOALLOC_MAX_LINES * 4);
 constexpr size_t NA_OCCOFF = NA_TOKOFF + na_up(((size_t)SAGE_NOALLOC_MAX_LINES + 1) * 4);
 constexpr size_t NA_TILES = NA_OCCOFF + na_up(((size_t)SAGE_NOALLOC_MAX_LINES + 1) * 4);
 constexpr size_t NA_TOTAL = NA_TILES + na_up(((size_t)SAGE_NOALLOC_MAX_LINES / SCAN_TILE + 2) * 4);
 constexpr size_t NA_FLAGS = NA_TOTAL + na_up(16);
-constexpr size_t NA_BYTES = NA_FLAGS + na_up(FLAG_COUNT * 4);                           // ~11.6 MiB
+constexpr size_t NA_BYTES = NA_FLAGS + na_up(FLAG_COUNT * 4);                           // ~10.6 MiB
 static __device__ __align__(256) unsigned char scratch[NA_BYTES];
 
 struct sage_ctx {
@@ -92,7 +91,7 @@ struct sage_ctx {
     int score_mode = 0;   // 0 = float32 storage when lossless for most rows, 1 = always float64 storage
 
     // scratch (grow-only; nothing is allocated in the steady state)
-    DevBuf M, Lp, ntok, tokoff, tile_sums, grand_total, tok_w0, occ_pos, set, seg_line_rel, seg_tok_off, set_base, set_mask, seg_pairs, desc, gcache, bucket_off, rec_a,
+    DevBuf M, ntok, tokoff, tile_sums, grand_total, tok_w0, occ_pos, set, seg_line_rel, seg_tok_off, set_base, set_mask, seg_pairs, desc, gcache, bucket_off, rec_a,
         nocc, occoff, occ_tok, occ_a, exact_list, exact_count, np_ab, dot_off, dots, pool, pool_cursor,
         np_all, pair_off, seg_first_occ, seg_tile_off, seg_bucket_base, seg_nbk_mask, cursor, giant_list, giant_count, tile_tab;
     int pool_factor = 8;  // id-pool words per occurrence (grown on overflow)
@@ -229,7 +228,6 @@ struct MatchBufs {
     const uint8_t* rem;         // bytes to the line end per text byte
     const int64_t* line_off;    // device line offsets, indexed from line 0 of `corpus`
     uint2* M;                   // [nb]
-    uint8_t* L;                 // [nb + 64] length plane: len1 of every position (what the line walks stream)
     uint32_t *ntok, *nocc;      // [nl]
     uint32_t *tokoff, *occoff;  // [nl + 1]
     uint32_t* tile_sums;        // [scan_tiles(nl)]
@@ -250,8 +248,8 @@ void launch_match_and_count(sage_ctx* c, const MatchBufs& B, int64_t line0, uint
         if (c->match_mode != 1) {
             const uint32_t pgrid = std::min<uint32_t>(cdiv(nb, 1024), (uint32_t)c->n_cu);
 #define SAGE_MATCH_LDS(NW_, ML_) do { \
-                if (c->match_mode == 0) k_match_lds<NW_, ML_, true><<<pgrid, 1024, 0, c->stream>>>(B.corpus, B.rem, pos0, (uint32_t)nb, v, B.M, B.L); \
-                else k_match_lds<NW_, ML_, false><<<pgrid, 1024, 0, c->stream>>>(B.corpus, B.rem, pos0, (uint32_t)nb, v, B.M, B.L); } while (0)
+                if (c->match_mode == 0) k_match_lds<NW_, ML_, true><<<pgrid, 1024, 0, c->stream>>>(B.corpus, B.rem, pos0, (uint32_t)nb, v, B.M); \
+                else k_match_lds<NW_, ML_, false><<<pgrid, 1024, 0, c->stream>>>(B.corpus, B.rem, pos0, (uint32_t)nb, v, B.M); } while (0)
             const int ml = c->max_len;      // the smallest instantiation that covers max_len
             if (ml <= 8) SAGE_MATCH_LDS(1, 8);
             else if (ml <= 12) SAGE_MATCH_LDS(2, 12);
@@ -262,15 +260,15 @@ void launch_match_and_count(sage_ctx* c, const MatchBufs& B, int64_t line0, uint
             else SAGE_MATCH_LDS(4, 32);
 #undef SAGE_MATCH_LDS
         } else switch (nw) {
-        case 1: k_match<1><<<grid, 256, 0, c->stream>>>(B.corpus, B.rem, pos0, (uint32_t)nb, v, B.M, B.L); break;
-        case 2: k_match<2><<<grid, 256, 0, c->stream>>>(B.corpus, B.rem, pos0, (uint32_t)nb, v, B.M, B.L); break;
-        case 3: k_match<3><<<grid, 256, 0, c->stream>>>(B.corpus, B.rem, pos0, (uint32_t)nb, v, B.M, B.L); break;
-        default: k_match<4><<<grid, 256, 0, c->stream>>>(B.corpus, B.rem, pos0, (uint32_t)nb, v, B.M, B.L); break;
+        case 1: k_match<1><<<grid, 256, 0, c->stream>>>(B.corpus, B.rem, pos0, (uint32_t)nb, v, B.M); break;
+        case 2: k_match<2><<<grid, 256, 0, c->stream>>>(B.corpus, B.rem, pos0, (uint32_t)nb, v, B.M); break;
+        case 3: k_match<3><<<grid, 256, 0, c->stream>>>(B.corpus, B.rem, pos0, (uint32_t)nb, v, B.M); break;
+        default: k_match<4><<<grid, 256, 0, c->stream>>>(B.corpus, B.rem, pos0, (uint32_t)nb, v, B.M); break;
         }
     }
     {
         Prof p(c, SAGE_K_WALK);
-        k_walk_count<<<cdiv(nl, 256), 256, 0, c->stream>>>(B.line_off, line0, nl, pos0, B.L, B.ntok, B.nocc, B.flags);
+        k_walk_count<<<cdiv(nl, 256), 256, 0, c->stream>>>(B.line_off, line0, nl, pos0, B.M, B.ntok, B.nocc, B.flags);
     }
     scan_u32_with(c, B.ntok, nl, B.tokoff, B.grand_total, B.tile_sums);
     scan_u32_with(c, B.nocc, nl, B.occoff, B.grand_total + 1, B.tile_sums);
@@ -284,14 +282,13 @@ int match_and_count(sage_ctx* c, int64_t line0, int64_t line1, uint64_t* out_tot
     if (nb >= 0xFFFFFF00ull) return fail(c, SAGE_E_LIMIT, "a batch must stay under 4 GiB of corpus bytes");
     int rc;
     if ((rc = ensure(c, c->M, std::max<uint64_t>(nb, 1) * sizeof(uint2)))) return rc;
-    if ((rc = ensure(c, c->Lp, nb + 64))) return rc;
     if ((rc = ensure(c, c->ntok, (size_t)nl * 4))) return rc;
     if ((rc = ensure(c, c->nocc, (size_t)nl * 4))) return rc;
     if ((rc = ensure(c, c->tokoff, ((size_t)nl + 1) * 4))) return rc;
     if ((rc = ensure(c, c->occoff, ((size_t)nl + 1) * 4))) return rc;
     if ((rc = ensure(c, c->grand_total, 16))) return rc;
     if ((rc = ensure(c, c->tile_sums, (size_t)scan_tiles(nl) * 4))) return rc;
-    const MatchBufs B{c->corpus.as<uint8_t>(), c->rem.as<uint8_t>(), c->line_off.as<int64_t>(), c->M.as<uint2>(), c->Lp.as<uint8_t>(),
+    const MatchBufs B{c->corpus.as<uint8_t>(), c->rem.as<uint8_t>(), c->line_off.as<int64_t>(), c->M.as<uint2>(),
                       c->ntok.as<uint32_t>(), c->nocc.as<uint32_t>(), c->tokoff.as<uint32_t>(), c->occoff.as<uint32_t>(),
                       c->tile_sums.as<uint32_t>(), c->grand_total.as<uint64_t>(), c->flags.as<uint32_t>()};
     launch_match_and_count(c, B, line0, nl, pos0, nb);
@@ -478,7 +475,7 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
             {
                 Prof p(c, SAGE_K_WALK);
                 k_walk_write<false><<<cdiv(nl, 256), 256, 0, c->stream>>>(
-                    c->line_off.as<int64_t>(), line0, nl, pos0, c->M.as<uint2>(), c->Lp.as<uint8_t>(), c->tokoff.as<uint32_t>(),
+                    c->line_off.as<int64_t>(), line0, nl, pos0, c->M.as<uint2>(), c->tokoff.as<uint32_t>(),
                     c->occoff.as<uint32_t>(), c->tok_w0.as<uint32_t>(), c->occ_pos.as<uint32_t>(),
                     c->occ_tok.as<uint32_t>(), nullptr, nullptr, nullptr);
             }
@@ -763,7 +760,7 @@ void sage_destroy(sage_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     collect_events(c);
     for (auto e : c->ev_free) (void)hipEventDestroy(e);
-    DevBuf* all[] = {&c->buckets, &c->keys, &c->ebk, &c->vk_bytes, &c->vk_off, &c->vk_ids, &c->byte_id, &c->direct2, &c->bloom, &c->pmask, &c->pmask8, &c->corpus, &c->rem, &c->line_off, &c->emb, &c->M, &c->Lp, &c->ntok,
+    DevBuf* all[] = {&c->buckets, &c->keys, &c->ebk, &c->vk_bytes, &c->vk_off, &c->vk_ids, &c->byte_id, &c->direct2, &c->bloom, &c->pmask, &c->pmask8, &c->corpus, &c->rem, &c->line_off, &c->emb, &c->M, &c->ntok,
                      &c->tokoff, &c->tile_sums, &c->grand_total, &c->tok_w0, &c->occ_pos, &c->set, &c->seg_line_rel,
                      &c->seg_tok_off, &c->set_base, &c->set_mask, &c->seg_pairs, &c->desc, &c->gcache, &c->bucket_off, &c->rec_a, &c->nocc, &c->occoff, &c->occ_tok,
                      &c->occ_a, &c->exact_list, &c->exact_count, &c->np_ab, &c->dot_off, &c->dots, &c->pool, &c->pool_cursor, &c->np_all, &c->pair_off, &c->seg_first_occ, &c->seg_tile_off,
@@ -953,7 +950,7 @@ static int w2v_tokenize_batch(sage_ctx* c, int64_t l0, int64_t l1, uint32_t* n_t
     if ((rc = ensure(c, c->occ_pos, (size_t)std::max(n_occ, 1u) * 4))) return rc;
     if ((rc = ensure(c, c->occ_tok, (size_t)std::max(n_occ, 1u) * 4))) return rc;
     k_walk_write<false><<<cdiv(nl, 256), 256, 0, c->stream>>>(
-        c->line_off.as<int64_t>(), l0, nl, c->h_line_off[l0], c->M.as<uint2>(), c->Lp.as<uint8_t>(), c->tokoff.as<uint32_t>(),
+        c->line_off.as<int64_t>(), l0, nl, c->h_line_off[l0], c->M.as<uint2>(), c->tokoff.as<uint32_t>(),
         c->occoff.as<uint32_t>(), c->tok_w0.as<uint32_t>(), c->occ_pos.as<uint32_t>(), c->occ_tok.as<uint32_t>(),
         nullptr, nullptr, nullptr);
     HIP_TRY(c, hipGetLastError());
@@ -1123,7 +1120,7 @@ int sage_tokenize(sage_ctx* c, int64_t line_begin, int64_t line_end, int32_t* ou
             {
                 Prof p(c, SAGE_K_WALK);
                 k_walk_write<true><<<cdiv(nl, 256), 256, 0, c->stream>>>(
-                    c->line_off.as<int64_t>(), l0, nl, c->h_line_off[l0], c->M.as<uint2>(), c->Lp.as<uint8_t>(), c->tokoff.as<uint32_t>(),
+                    c->line_off.as<int64_t>(), l0, nl, c->h_line_off[l0], c->M.as<uint2>(), c->tokoff.as<uint32_t>(),
                     nullptr, nullptr, nullptr, nullptr, c->ex_ids.as<int32_t>(), c->ex_starts.as<int32_t>(),
                     c->ex_widths.as<int32_t>());
             }
@@ -1170,7 +1167,7 @@ int sage_tokenize_noalloc(sage_ctx* c, const uint8_t* d_text, int64_t n_bytes, c
     unsigned char* S = c->na_scratch;          // never the array's name: see the note at its definition
     uint8_t* text = S + NA_TEXT;
     uint8_t* rem = S + NA_REM;
-    const MatchBufs B{text, rem, d_line_offsets, reinterpret_cast<uint2*>(S + NA_M), S + NA_LEN,
+    const MatchBufs B{text, rem, d_line_offsets, reinterpret_cast<uint2*>(S + NA_M),
                       reinterpret_cast<uint32_t*>(S + NA_NTOK), reinterpret_cast<uint32_t*>(S + NA_NOCC),
                       reinterpret_cast<uint32_t*>(S + NA_TOKOFF), reinterpret_cast<uint32_t*>(S + NA_OCCOFF),
                       reinterpret_cast<uint32_t*>(S + NA_TILES), reinterpret_cast<uint64_t*>(S + NA_TOTAL),
@@ -1193,7 +1190,7 @@ int sage_tokenize_noalloc(sage_ctx* c, const uint8_t* d_text, int64_t n_bytes, c
     if (d_counts) k_widen_counts<<<cdiv(nl, 256), 256, 0, c->stream>>>(B.ntok, nl, d_counts);
     if (want_tokens && total) {
         if ((int64_t)total > capacity) return fail(c, SAGE_E_ARG, "token capacity too small");
-        k_walk_write<true><<<cdiv(nl, 256), 256, 0, c->stream>>>(d_line_offsets, 0, nl, 0, B.M, B.L, B.tokoff, nullptr, nullptr,
+        k_walk_write<true><<<cdiv(nl, 256), 256, 0, c->stream>>>(d_line_offsets, 0, nl, 0, B.M, B.tokoff, nullptr, nullptr,
                                                                 nullptr, nullptr, d_ids, d_starts, d_widths);
     }
     HIP_TRY(c, hipGetLastError());

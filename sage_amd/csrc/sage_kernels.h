@@ -57,8 +57,7 @@ __global__ __launch_bounds__(256) void k_line_remaining(const int64_t* __restric
 // ----------------------------------------------------------------------------------------------------------
 template <int NW>  // key words of 8 bytes: handles max_len <= 8*NW
 __global__ __launch_bounds__(256) void k_match(const uint8_t* __restrict__ corpus, const uint8_t* __restrict__ rem,
-                                               int64_t pos0, uint32_t count, VocabDev v, uint2* __restrict__ M,
-                                               uint8_t* __restrict__ Lp) {
+                                               int64_t pos0, uint32_t count, VocabDev v, uint2* __restrict__ M) {
     constexpr int ML = 8 * NW;
     constexpr int NDW = (256 + ML + 8) / 4 + 1;
     __shared__ uint32_t text[NDW];
@@ -136,7 +135,6 @@ __global__ __launch_bounds__(256) void k_match(const uint8_t* __restrict__ corpu
     }
     const uint32_t ends1 = len1 == (uint32_t)rem[blk0 + tid] ? 0x80000000u : 0u;
     M[rel] = make_uint2(id1 | (len1 << 20) | ends1, id2 | (len2 << 20));
-    Lp[rel] = (uint8_t)len1;
 }
 
 // ----------------------------------------------------------------------------------------------------------
@@ -524,8 +522,7 @@ __device__ __forceinline__ void probe_queued(const VocabDev& v, uint32_t cand, c
 // for max_len 17 hashes 16 prefix lengths, not the 23 a 24-byte window would allow.
 template <int NW, int ML = 8 * NW, bool QUEUED = true>
 __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ corpus, const uint8_t* __restrict__ rem,
-                                                    int64_t pos0, uint32_t count, VocabDev v, uint2* __restrict__ M,
-                                                    uint8_t* __restrict__ Lp) {
+                                                    int64_t pos0, uint32_t count, VocabDev v, uint2* __restrict__ M) {
     static_assert(ML <= 8 * NW && ML > 8 * (NW - 1), "ML must need exactly NW key words");
     constexpr int WDW = (64 + ML + 8) / 4 + 1;   // dwords of text one wave stages for its 64 positions (<= 27)
     __shared__ uint32_t bloom[SAGE_BLOOM_BITS / 32];
@@ -635,10 +632,8 @@ __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ 
         // longest of them in any case; with a single match m2 is 0 = "no second match", len2 == 0 iff len1 == 1)
         // streamed once: keep it out of the way of the table and key planes in L2
         const uint32_t ends1 = SAGE_M_LEN(top.m1) == rm ? 0x80000000u : 0u;
-        if (rel < count) {
+        if (rel < count)
             __builtin_nontemporal_store((uint64_t)(top.m1 | ends1) | ((uint64_t)top.m2 << 32), reinterpret_cast<uint64_t*>(M + rel));
-            Lp[rel] = (uint8_t)SAGE_M_LEN(top.m1);     // the length plane the line walks stream (64 bytes per wave)
-        }
     }
 }
 
@@ -646,17 +641,8 @@ __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ 
 // K2a  base chain: one thread per line follows p -> p + len1(p) (model.py:89-99).  Pass 1 counts tokens, pass 2
 // (after an exclusive scan of the counts) writes the compact token arrays.
 // ----------------------------------------------------------------------------------------------------------
-// The chain itself runs on the LENGTH PLANE (one byte per position, written by the matcher beside M): a 128-byte line
-// of it covers ~20 tokens, one of M (8 bytes per position) 2-3, so the dependent step p -> p + len mostly hits a line
-// the thread has just used.
-struct LenStream {       // (a register window of 16-byte chunks with loads running ahead measured slower: rotating the window
-    const uint8_t* L;    //  makes every step wait for all loads in flight; the plain byte chain below hits a cached line ~20 times)
-    __device__ __forceinline__ void open(const uint8_t* Lp, uint32_t, uint32_t) { L = Lp; }
-    __device__ __forceinline__ uint32_t len_at(uint32_t p) const { return max((uint32_t)L[p], 1u); }   // (never 0; the max keeps any bug from looping)
-};
-
 __global__ __launch_bounds__(256) void k_walk_count(const int64_t* __restrict__ line_off, int64_t line0,
-                                                    uint32_t n_lines, int64_t pos0, const uint8_t* __restrict__ Lp,
+                                                    uint32_t n_lines, int64_t pos0, const uint2* __restrict__ M,
                                                     uint32_t* __restrict__ ntok, uint32_t* __restrict__ nocc,
                                                     uint32_t* __restrict__ flags) {
     uint32_t l = blockIdx.x * 256u + threadIdx.x;
@@ -664,10 +650,8 @@ __global__ __launch_bounds__(256) void k_walk_count(const int64_t* __restrict__ 
     uint32_t p = (uint32_t)(line_off[line0 + l] - pos0), e = (uint32_t)(line_off[line0 + l + 1] - pos0);
     if (p == e) flags[FLAG_EMPTY_LINE] = 1;
     uint32_t c = 0, mb = 0;
-    LenStream ls;
-    ls.open(Lp, p, e);
     while (p < e) {
-        const uint32_t len = ls.len_at(p);
+        const uint32_t len = SAGE_M_LEN(M[p].x);
         p += len; ++c; mb += len > 1u;
     }
     ntok[l] = c;
@@ -705,7 +689,6 @@ struct GroupedWriter {
 template <bool EXPORT>
 __global__ __launch_bounds__(256) void k_walk_write(const int64_t* __restrict__ line_off, int64_t line0,
                                                     uint32_t n_lines, int64_t pos0, const uint2* __restrict__ M,
-                                                    const uint8_t* __restrict__ Lp,
                                                     const uint32_t* __restrict__ tok_off,
                                                     const uint32_t* __restrict__ occ_off,
                                                     uint32_t* __restrict__ tok_w0, uint32_t* __restrict__ occ_pos,
@@ -721,37 +704,19 @@ __global__ __launch_bounds__(256) void k_walk_write(const int64_t* __restrict__ 
     uint32_t o = EXPORT ? 0u : occ_off[l];
     GroupedWriter gw_tok, gw_occ, gw_pos;
     if (!EXPORT) { gw_tok.init(tok_w0, t); gw_occ.init(occ_tok, o); gw_pos.init(occ_pos, o); }
-    // eight tokens at a time: their positions from the length plane (registers), then their ids from M with all eight
-    // loads in flight together
-    constexpr int WG = 8;
-    LenStream ls;
-    ls.open(Lp, p, e);
     while (p < e) {
-        uint32_t pp[WG], mm[WG];
-        int n = 0;
-#pragma unroll
-        for (int i = 0; i < WG; ++i) {
-            pp[i] = p;
-            if (p < e) { p += ls.len_at(p); ++n; }
+        const uint32_t m = M[p].x;
+        if (EXPORT) {
+            ex_ids[t] = (int32_t)SAGE_M_ID(m);
+            ex_starts[t] = (int32_t)(p - p_begin);
+            ex_widths[t] = (int32_t)SAGE_M_LEN(m);
+        } else {
+            const uint32_t after = nt - 1u - c;
+            gw_tok.put(t, SAGE_M_ID(m) | ((c < 3u ? c : 3u) << 20) | ((after < 3u ? after : 3u) << 22));
+            if (SAGE_M_LEN(m) > 1u) { gw_occ.put(o, t); gw_pos.put(o, p); ++o; }   // compact list of the tokens that get ablated
         }
-#pragma unroll
-        for (int i = 0; i < WG; ++i) mm[i] = i < n ? M[pp[i]].x : 0u;
-#pragma unroll
-        for (int i = 0; i < WG; ++i) {
-            if (i < n) {
-                const uint32_t m = mm[i];
-                if (EXPORT) {
-                    ex_ids[t] = (int32_t)SAGE_M_ID(m);
-                    ex_starts[t] = (int32_t)(pp[i] - p_begin);
-                    ex_widths[t] = (int32_t)SAGE_M_LEN(m);
-                } else {
-                    const uint32_t after = nt - 1u - c;
-                    gw_tok.put(t, SAGE_M_ID(m) | ((c < 3u ? c : 3u) << 20) | ((after < 3u ? after : 3u) << 22));
-                    if (SAGE_M_LEN(m) > 1u) { gw_occ.put(o, t); gw_pos.put(o, pp[i]); ++o; }   // compact list of the tokens that get ablated
-                }
-                ++t; ++c;
-            }
-        }
+        p += SAGE_M_LEN(m);
+        ++t; ++c;
     }
     if (!EXPORT) { gw_tok.finish(t); gw_occ.finish(o); gw_pos.finish(o); }
 }
