@@ -137,7 +137,8 @@ int sage_set_profiling(sage_ctx* ctx, int enabled);
 int sage_reset_kernel_times(sage_ctx* ctx);
 int sage_get_kernel_times(sage_ctx* ctx, double* out_ms /*[SAGE_K_NCLASSES]*/, int64_t* out_launches /*[SAGE_K_NCLASSES]*/);
 
-/* Tunables: scratch is sized for batches of at most `bytes` corpus bytes (default 256 MiB). */
+/* Tunables: scratch is sized for batches of at most `bytes` corpus bytes (default 512 MiB; a batch whose
+   position pairs would overflow the 32-bit offsets makes the step halve it and start over). */
 int sage_set_batch_bytes(sage_ctx* ctx, int64_t bytes);
 
 /* Matcher variant: 0 = persistent blocks with the 128 KiB presence filter in LDS, candidates compacted through an LDS

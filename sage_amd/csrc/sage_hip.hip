@@ -102,7 +102,8 @@ struct sage_ctx {
     DevBuf loss, occ, hist, stats, flags;
     DevBuf loss_fix;              // deterministic mode: 128-bit fixed-point loss sums, two words per id
     bool deterministic = false;
-    int64_t batch_bytes = 256ll << 20;
+    uint64_t pair_limit = 0xFFFFFF00ull;   // 32-bit pair / dot offsets per batch (SAGE_TEST_PAIR_LIMIT lowers it: test hook)
+    int64_t batch_bytes = 512ll << 20;   // fewer, larger batches: the line walks last as long as a batch's longest line (4.9 -> 3.9 ms from two batches to one)
     int set_factor = 16;
 
     // measurement
@@ -439,6 +440,7 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
         uint64_t total_tokens = 0, total_bytes = 0, total_occ = 0;
 
         int64_t sa = 0;
+        bool shrink = false;
         while (sa < n_seg) {
             // a batch = as many whole segments as fit in batch_bytes (at least one)
             int64_t sb = sa + 1;
@@ -552,7 +554,11 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
                 HIP_TRY(c, hipMemcpyAsync(gt2, c->grand_total.p, 16, hipMemcpyDeviceToHost, c->stream));
                 HIP_TRY(c, hipStreamSynchronize(c->stream));
                 n_dots = gt2[1];
-                if (gt2[0] >= 0xFFFFFF00ull) return fail(c, SAGE_E_LIMIT, "a batch must stay under 2^32 position pairs");
+                if (gt2[0] >= c->pair_limit) {   // 32-bit pair offsets: halve the batches and redo the step
+                    if (nsb <= 1) return fail(c, SAGE_E_LIMIT, "a count segment must stay under 2^32 position pairs");
+                    shrink = true;
+                    break;
+                }
                 // buckets per segment: a power of two that keeps a bucket near 8k records (one pass of the 16k-slot LDS set)
                 std::vector<uint32_t> bbase(nsb + 1), bmask(nsb);
                 uint32_t nbk_total = 0;
@@ -668,11 +674,22 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
                                                                c->stats.as<unsigned long long>(), c->flags.as<uint32_t>());
                 }
             }
-            if (n_dots >= 0xFFFFFF00ull) return fail(c, SAGE_E_LIMIT, "a batch must stay under 2^32 ablated-window pairs");
+            if (n_dots >= c->pair_limit) {
+                if (nsb <= 1) return fail(c, SAGE_E_LIMIT, "a count segment must stay under 2^32 ablated-window pairs");
+                shrink = true;
+                break;
+            }
             if ((rc = ensure(c, c->dots, std::max<uint64_t>(n_dots, 1) * 8))) return rc;
             launch_score(c, A.tok_w0, n_tok, n_occ);
             HIP_TRY(c, hipGetLastError());
             sa = sb;
+        }
+        if (shrink) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            collect_events(c);
+            if (c->batch_bytes <= 4096) return fail(c, SAGE_E_LIMIT, "position pairs overflow 32-bit offsets even in the smallest batches");
+            c->batch_bytes = std::max<int64_t>(c->batch_bytes / 2, 4096);     // every retry halves it: the loop ends
+            continue;
         }
         if (c->deterministic)
             k_fix_finish<<<cdiv((uint64_t)vsize, 256), 256, 0, c->stream>>>(c->loss_fix.as<unsigned long long>(), (uint32_t)vsize,
@@ -747,6 +764,7 @@ int sage_create(int device, sage_ctx** out_ctx) {
     if (const char* e = std::getenv("SAGE_POOL_FACTOR")) { const int v = std::atoi(e); if (v >= 0 && v <= 64) c->pool_factor = v; }
     if (scratch_for_device(device, &c->na_scratch) != hipSuccess) { delete c; return SAGE_E_HIP; }   // device is current
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SAGE_E_HIP; }
+    if (const char* e = std::getenv("SAGE_TEST_PAIR_LIMIT")) { const long long x = std::atoll(e); if (x > 0) c->pair_limit = (uint64_t)x; }
     if (hipMalloc(&c->flags.p, FLAG_COUNT * 4) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return SAGE_E_HIP; }
     c->flags.cap = FLAG_COUNT * 4;
     (void)hipMemset(c->flags.p, 0, FLAG_COUNT * 4);
@@ -771,6 +789,13 @@ void sage_destroy(sage_ctx* c) {
     delete c;
 }
 
+#ifdef MATCH_STATS
+extern "C" int sage_debug_match_stats(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_match_dbg), 16 * 8) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_match_dbg), z, 16 * 8) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
 const char* sage_last_error(const sage_ctx* c) { return c ? c->err.c_str() : "null context"; }
 
 int sage_set_vocab(sage_ctx* c, const uint8_t* key_bytes, const int64_t* key_offsets, const int32_t* key_ids,

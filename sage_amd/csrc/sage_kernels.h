@@ -425,6 +425,9 @@ __device__ __forceinline__ bool probe_exact_e(const VocabDev& v, uint32_t b, con
 // entry index without a scan), and the wave then probes 64 REAL candidates per round: lane e takes entry e, fetches
 // the text words of the entry's position from the owner lane's registers (ds_bpermute), probes, and leaves the result
 // in the entry; the owners fold their results afterwards.  A class larger than the queue is done in windows.
+#ifdef MATCH_STATS
+__device__ unsigned long long g_match_dbg[16];
+#endif
 #define MQ_CAP 224u      // entries per wave: 16 waves x 224 x 8 B = 28 KiB beside the 128 KiB filter
 template <int NW, int JLO, int JHI, int ML>
 __device__ __forceinline__ void probe_queued(const VocabDev& v, uint32_t cand, const uint32_t (&fh)[ML + 1],
@@ -441,6 +444,9 @@ __device__ __forceinline__ void probe_queued(const VocabDev& v, uint32_t cand, c
         pre[i] = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
         total += (uint32_t)__popcll(m);
     }
+#ifdef MATCH_STATS
+    if (lane == 0 && total) atomicAdd(&g_match_dbg[2 * (JLO >= 13 ? 0 : JLO >= 9 ? 1 : JLO >= 7 ? 2 : JLO >= 5 ? 3 : 4)], (unsigned long long)total);
+#endif
     for (uint32_t w0 = 0; w0 < total; w0 += MQ_CAP) {        // wave-uniform
 #pragma unroll
         for (int i = 0; i < N; ++i) {
@@ -507,6 +513,10 @@ __device__ __forceinline__ void probe_queued(const VocabDev& v, uint32_t cand, c
             // rare: the bucket is full (the key may live in the next one), or a 12-byte prefix matched a different key
             if (valid && !eq && (hit || meta.w != SAGE_SLOT_EMPTY)) eq = probe_exact_e<NW>(v, b, Ws, j, id);
             if (valid) q[e].x = eq ? (id | (j << 20)) : 0u;
+#ifdef MATCH_STATS
+            { const unsigned long long hb = __ballot(valid && eq);
+              if (lane == 0 && hb) atomicAdd(&g_match_dbg[2 * (JLO >= 13 ? 0 : JLO >= 9 ? 1 : JLO >= 7 ? 2 : JLO >= 5 ? 3 : 4) + 1], (unsigned long long)__popcll(hb)); }
+#endif
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll

@@ -120,3 +120,27 @@ def test_deterministic_mode_is_bit_identical(world):
         eng.set_batch_bytes(256 << 20)
     d = eng.ablation_step(bounds)
     _same(ref, d, rtol=1e-12)
+
+
+def test_batches_shrink_when_pair_offsets_would_overflow(monkeypatch):
+    """32-bit pair and dot offsets bound a batch; a batch above the bound makes the step halve batch_bytes and start
+    over (SAGE_TEST_PAIR_LIMIT lowers the bound so that a small corpus reaches it).  Results must not change."""
+    from sage_amd import synth
+    from sage_amd._lib import HipSage
+    from sage_amd.parallel import segment_line_bounds
+    corpus, off = synth.make_corpus(3000, seed=21, style="en", n_types=4000, mean_log_words=2.8)
+    vocab = synth.make_vocab(corpus, off, 4000, 16, sample_bytes=400_000)
+    emb = synth.make_embeddings(len(vocab), 50, seed=3)
+    bounds = segment_line_bounds(len(off) - 1, 2, flush=100)
+    def run():
+        eng = HipSage(0)
+        try:
+            eng.set_vocab(vocab, None, 16); eng.set_corpus(corpus, off); eng.set_embeddings(emb)
+            return eng.ablation_step(bounds), eng.step_stats()
+        finally:
+            eng.close()
+    ref, st = run()
+    assert st["pairs"] > 400_000
+    monkeypatch.setenv("SAGE_TEST_PAIR_LIMIT", str(st["pairs"] // 5))     # whole corpus in one batch: 5x the bound
+    got, _ = run()
+    _same(ref, got)

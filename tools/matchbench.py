@@ -25,3 +25,17 @@ for m in modes:
     for _ in range(3): e.token_counts(0, len(off) - 1)
     kt = e.kernel_times(); print("mode", m, "match ms per pass", kt['match'][0] / 3, "bytes", len(corpus), "tokens equal to first mode:", same, flush=True)
     e.set_profiling(False)
+
+try:
+    import ctypes as C
+    lib = C.CDLL(str(_lib.LIB_PATH))
+    out = (C.c_ulonglong * 16)()
+    lib.sage_debug_match_stats(out, 1)            # reset
+    e.set_match_mode(0); e.token_counts(0, len(off) - 1)
+    lib.sage_debug_match_stats(out, 0)
+    names = ["13+", "9..12", "7..8", "5..6", "3..4"]
+    nb = len(corpus)
+    for i, n in enumerate(names):
+        print(f"class {n}: candidates per byte {out[2*i]/nb:.3f}, hits per byte {out[2*i+1]/nb:.3f}")
+except AttributeError:
+    pass
