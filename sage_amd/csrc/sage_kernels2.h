@@ -135,17 +135,28 @@ struct Ablation {
 };
 
 // ldx(p) returns M[p].x; the kernels pass a loader that serves a staged span from LDS.
+// The occurrence's own words (token word, match entry, the two tokens before it) are passed in: k_describe loads them
+// while its span of M is still on the way instead of after it.
+struct OccWords { uint32_t w0, prev1, prev2; uint2 m0; };
+__device__ __forceinline__ OccWords load_occ_words(const WalkArrays& A, uint32_t t, uint32_t p0) {
+    OccWords w;
+    w.w0 = A.tok_w0[t];
+    w.m0 = A.M[p0];
+    w.prev1 = t >= 1u ? A.tok_w0[t - 1] : 0u;     // used only when the token has that many predecessors in its line
+    w.prev2 = t >= 2u ? A.tok_w0[t - 2] : 0u;
+    return w;
+}
 template <class LoadX, class Emit>
-__device__ __forceinline__ Ablation walk_occurrence(const WalkArrays& A, uint32_t t, uint32_t p0, LoadX&& ldx, Emit&& emit) {
+__device__ __forceinline__ Ablation walk_occurrence(const WalkArrays& A, const OccWords& ow, uint32_t p0, LoadX&& ldx, Emit&& emit) {
     Ablation r;
-    const uint32_t w0 = A.tok_w0[t];
-    const uint2 m0 = A.M[p0];
+    const uint32_t w0 = ow.w0;
+    const uint2 m0 = ow.m0;
     r.a = SAGE_T_ID(w0);
     const uint32_t loc3 = SAGE_T_LOC3(w0);
     r.pl = loc3 < 2u ? loc3 : 2u;                              // padleft = min(pad, loc), model.py:218
     r.k = 0; r.m = 1; r.pr = 0; r.never = false; r.complete = false;
-    if (r.pl == 2u && !emit(SAGE_T_ID(A.tok_w0[t - 2]))) return r;
-    if (r.pl >= 1u && !emit(SAGE_T_ID(A.tok_w0[t - 1]))) return r;
+    if (r.pl == 2u && !emit(SAGE_T_ID(ow.prev2))) return r;
+    if (r.pl >= 1u && !emit(SAGE_T_ID(ow.prev1))) return r;
     // first piece: longest key of at most width-1 bytes = the second-longest match
     if (!emit(SAGE_M_ID(m0.y))) return r;
     r.k = 1;
@@ -184,6 +195,11 @@ __device__ __forceinline__ Ablation walk_occurrence(const WalkArrays& A, uint32_
     }
     r.complete = true;
     return r;
+}
+
+template <class LoadX, class Emit>
+__device__ __forceinline__ Ablation walk_occurrence(const WalkArrays& A, uint32_t t, uint32_t p0, LoadX&& ldx, Emit&& emit) {
+    return walk_occurrence(A, load_occ_words(A, t, p0), p0, ldx, emit);
 }
 
 // Position pairs at distance 1 or 2 of a window [pl pads | c centre elements | pr pads] with at least one end in
@@ -253,12 +269,17 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
         const uint32_t item = base + threadIdx.x;
         const bool live = item < n_items;
         const uint32_t o = !live ? 0u : (LONG ? D.long_list[item] : item);
-        uint32_t P0 = 0;
+        uint32_t P0 = 0, t_pre = 0, p0_pre = 0;
+        OccWords ow{0u, 0u, 0u, make_uint2(0u, 0u)};
         if (!LONG) {
             // 256 consecutive occurrences cover ~1.5 KB of text; their walks stay within a few hundred bytes of it.
             // Every dependent step of a walk is then an LDS read instead of an L2 round trip.
+            // the occurrence's own loads (two dependent levels) are issued with the span's, not after the barrier
+            t_pre = live ? occ_tok[o] : 0u;
+            p0_pre = live ? A.occ_pos[o] : 0u;
             P0 = A.occ_pos[base];
             for (uint32_t i = threadIdx.x; i < DESC_SPAN; i += 256u) span[i] = (P0 + i) < A.n_pos ? A.M[P0 + i].x : 0u;
+            if (live) ow = load_occ_words(A, t_pre, p0_pre);
             __syncthreads();
         }
         auto ldx = [&](uint32_t p) -> uint32_t {
@@ -266,8 +287,8 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
             if (!LONG && d < (uint32_t)DESC_SPAN) return span[d];
             return A.M[p].x;
         };
-        const uint32_t t = live ? occ_tok[o] : 0u;
-        const uint32_t p0 = live ? A.occ_pos[o] : 0u;
+        const uint32_t t = LONG ? (live ? occ_tok[o] : 0u) : t_pre;
+        const uint32_t p0 = LONG ? (live ? A.occ_pos[o] : 0u) : p0_pre;
         const uint32_t seg = live ? find_segment(S, t) : 0xFFFFFFFFu;
         unsigned long long my_pairs = 0;
         bool is_long = false, done = false, bad = false;
@@ -275,7 +296,7 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
             uint32_t L = 0;
             Ablation w;
             if (!LONG) {
-                w = walk_occurrence(A, t, p0, ldx, [&](uint32_t id) {
+                w = walk_occurrence(A, ow, p0, ldx, [&](uint32_t id) {
                     if (L == SAGE_DESC_MAXWIN) return false;     // does not fit: leave it to the long pass
                     my[1 + L] = id;
                     ++L;
