@@ -715,17 +715,27 @@ __global__ __launch_bounds__(256) void k_logsig(const uint4* __restrict__ desc, 
     const double* Gd = reinterpret_cast<const double*>(Gc);
     // DET: a term that is not finite cannot be held in fixed point; it goes into the float64 vector of its ablated id
     auto stray = [&](uint32_t o, double term) { unsafeAtomicAdd(&loss[occ_a[o] & SAGE_ID_MASK], term); };
+    // the per-occurrence words of the NEXT tile are loaded while this one is processed (a first level of dependent loads
+    // off every tile's critical path)
+    uint32_t nx_off = 0, nx_end = 0, nx_a = 0, nx_t = 0;
+    auto prefetch = [&](uint32_t o0) {
+        if (o0 >= n_occ) return;
+        const uint32_t nt = min((uint32_t)LOGSIG_TILE, n_occ - o0);
+        if (threadIdx.x < nt) { nx_off = dot_off[o0 + threadIdx.x]; nx_a = occ_a[o0 + threadIdx.x]; nx_t = occ_tok[o0 + threadIdx.x]; }
+        if (threadIdx.x == 0) nx_end = dot_off[o0 + nt];
+    };
+    prefetch(blockIdx.x * LOGSIG_TILE);
     for (uint32_t o0 = blockIdx.x * LOGSIG_TILE; o0 < n_occ; o0 += gridDim.x * LOGSIG_TILE) {
         const uint32_t nt = min((uint32_t)LOGSIG_TILE, n_occ - o0);   // occurrences of this tile
         __syncthreads();
-        if (threadIdx.x < nt) off[threadIdx.x] = dot_off[o0 + threadIdx.x];
-        if (threadIdx.x == 0) off[nt] = dot_off[o0 + nt];   // nt can be 256: there is no thread 256
+        if (threadIdx.x < nt) off[threadIdx.x] = nx_off;
+        if (threadIdx.x == 0) off[nt] = nx_end;             // nt can be 256: there is no thread 256
         osum0[threadIdx.x] = 0ull;
         if (DET) osum1[threadIdx.x] = 0ull;
-        // phase-2 operands are independent of phase 1: issue their loads first
         const uint32_t o = o0 + threadIdx.x;
         uint32_t t = 0, a_w0 = 0;
-        if (threadIdx.x < nt) { a_w0 = occ_a[o]; t = occ_tok[o]; }
+        if (threadIdx.x < nt) { a_w0 = nx_a; t = nx_t; }
+        prefetch(o0 + gridDim.x * LOGSIG_TILE);
         __syncthreads();
         // ---- loads of both phases issued together: the pair-cache window of this thread's occurrence (phase 2), the
         // ablated id, and the first LOGSIG_PF dots of this thread's slice (phase 1) -- one exposed latency per tile
