@@ -109,8 +109,8 @@ __device__ __forceinline__ void load_inline(const uint4* __restrict__ desc, cons
     const uint32_t nb = (x.d[0] & SAGE_DH_OVER) ? 0u : pl + SAGE_DH_M(x.d[0]) + SAGE_DH_PR(x.d[0]);
 #pragma unroll
     for (int i = 0; i < BASE_PF; ++i) x.base[i] = (uint32_t)i < nb ? SAGE_T_ID(tok_w0[x.t - pl + (uint32_t)i]) : 0u;
-    x.a = (x.d[0] & SAGE_DH_OVER) ? SAGE_T_ID(tok_w0[x.t]) : x.base[pl < (uint32_t)BASE_PF ? pl : 0];
-    if (pl >= (uint32_t)BASE_PF) x.a = SAGE_T_ID(tok_w0[x.t]);
+    // (pl <= 2; a select chain, not x.base[pl]: one dynamic index would put the whole struct into scratch memory)
+    x.a = (x.d[0] & SAGE_DH_OVER) ? SAGE_T_ID(tok_w0[x.t]) : (pl == 0u ? x.base[0] : pl == 1u ? x.base[1] : x.base[2]);
 }
 
 __device__ __forceinline__ uint64_t make_key(uint32_t a, uint32_t lo, uint32_t hi) {
