@@ -429,12 +429,14 @@ __global__ __launch_bounds__(256) void k_key_giant(const uint4* __restrict__ des
 // low words claimed by a 32-bit compare-and-swap and high words stored afterwards, 15.7 ms.  Without the insertions the
 // kernel takes 4.5 ms: it is bound by LDS atomic throughput.)
 __device__ __forceinline__ uint32_t lds_set3_insert(unsigned long long* set, uint64_t key, uint32_t* flags) {
-    uint32_t s = sage_key_hash_b(key) & (SET3_SLOTS - 1u);
+    const uint32_t hb = sage_key_hash_b(key);
+    uint32_t s = hb & (SET3_SLOTS - 1u);
+    const uint32_t step = (hb >> 14) | 1u;               // odd: visits every slot of the power-of-two table
     for (uint32_t probes = 0; probes < SET3_SLOTS; ++probes) {
         const unsigned long long old = atomicCAS(&set[s], (unsigned long long)SAGE_SET_EMPTY, (unsigned long long)key);
         if (old == SAGE_SET_EMPTY) return ((uint32_t)(key >> 20) & SAGE_ID_MASK) == ((uint32_t)key & SAGE_ID_MASK) ? 1u : 2u;
         if (old == key) return 0u;
-        s = (s + 1u) & (SET3_SLOTS - 1u);
+        s = (s + step) & (SET3_SLOTS - 1u);
     }
     flags[FLAG_SET_OVERFLOW] = 1;
     return 0u;
