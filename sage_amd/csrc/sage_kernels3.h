@@ -424,10 +424,12 @@ __global__ __launch_bounds__(256) void k_key_giant(const uint4* __restrict__ des
     }
 }
 
-// (Measured alternatives, all slower on the bench corpus at 12.4 ms for this kernel: every record of a thread probing in
-// the same round, 17.5 ms; lanes that move on to their next record as soon as a probe ends, 20.8 ms; a set split into
-// low words claimed by a 32-bit compare-and-swap and high words stored afterwards, 15.7 ms.  Without the insertions the
-// kernel takes 4.5 ms: it is bound by LDS atomic throughput.)
+// Double hashing (an odd step from the key's own hash), not linear probing: half of the records are repeats of keys that
+// are already in the set, and behind a cluster every repeat walks the cluster again while its wave waits (12.3 -> 9.7 ms
+// for the kernel).  Measured alternatives, all slower: the first probe of a thread's eight records in flight together
+// (10.9 ms), every record of a thread probing in the same round, lanes that move on to their next record as soon as a
+// probe ends, a per-wave queue that probes the stragglers densely, a set split into 32-bit claim words + stored high
+// words, two half-full passes per bucket (11.9 ms).  Without the insertions the kernel takes 4.5 ms.
 __device__ __forceinline__ uint32_t lds_set3_insert(unsigned long long* set, uint64_t key, uint32_t* flags) {
     const uint32_t hb = sage_key_hash_b(key);
     uint32_t s = hb & (SET3_SLOTS - 1u);
