@@ -838,6 +838,7 @@ int sage_set_vocab(sage_ctx* c, const uint8_t* key_bytes, const int64_t* key_off
     const bool pm16 = max_len <= 16;      // the matcher instantiations for max_len <= 16 read 16-bit prefix-table entries
     const size_t total_key_bytes = (size_t)key_offsets[n_keys];
     int rc;
+    c->have_vocab = false;      // the tables are rewritten in place: no vocabulary until all of them are complete
     if ((rc = ensure(c, c->buckets, nbuckets * 16))) return rc;
     if ((rc = ensure(c, c->keys, key_plane * (size_t)nw * 8))) return rc;
     if ((rc = ensure(c, c->ebk, (size_t)enb * 64))) return rc;
@@ -872,7 +873,6 @@ int sage_set_vocab(sage_ctx* c, const uint8_t* key_bytes, const int64_t* key_off
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (int b = 0; b < 256; ++b)
         if (byte_id[b] == SAGE_SLOT_EMPTY) {
-            c->have_vocab = false;
             char msg[64];
             std::snprintf(msg, sizeof msg, "missing byte 0x%02x", b);
             return fail(c, SAGE_E_MISSING_BYTE, msg);
