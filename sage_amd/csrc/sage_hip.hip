@@ -349,6 +349,23 @@ void launch_dots(sage_ctx* c, const T* emb, uint32_t n_occ, const uint32_t* list
         c->desc.as<uint4>(), c->pool.as<uint32_t>(), n_occ, c->dot_off.as<uint32_t>(), emb, (uint32_t)c->emb_rows,
         (uint32_t)c->dp, c->dots.as<double>(), c->flags.as<uint32_t>(), list, list_count);
 }
+// the float64 pass over the inexact list with float32 rows where the copy holds them (k_dots<..., MIXED>)
+template <int G, int EPL>
+void launch_dots_mixed(sage_ctx* c, uint32_t n_occ) {
+    Prof p(c, SAGE_K_FIX);
+    static std::atomic<int> cached{0};
+    int per_cu = cached.load(std::memory_order_relaxed);
+    if (per_cu == 0) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_dots<G, EPL, double, 5, true>, 256, 0) != hipSuccess || per_cu < 1)
+            per_cu = 4;
+        cached.store(per_cu, std::memory_order_relaxed);
+    }
+    const uint32_t grid = std::min<uint32_t>(cdiv(n_occ, 256 / G), (uint32_t)c->n_cu * (uint32_t)std::max(per_cu, 1));
+    k_dots<G, EPL, double, 5, true><<<grid, 256, 0, c->stream>>>(
+        c->desc.as<uint4>(), c->pool.as<uint32_t>(), n_occ, c->dot_off.as<uint32_t>(), c->emb.as<double>(), (uint32_t)c->emb_rows,
+        (uint32_t)c->dp, c->dots.as<double>(), c->flags.as<uint32_t>(), c->inex_list.as<uint32_t>(), c->inex_count.as<uint32_t>(),
+        c->emb32.as<float>(), c->inexact.as<uint32_t>());
+}
 
 // instantiation per padded row width: float32 rows are whole 16-byte loads of 4 elements, float64 rows of 2
 #define SAGE_BY_WIDTH_F32(FN, ...)                       \
@@ -391,7 +408,7 @@ void launch_score(sage_ctx* c, const uint32_t* tok_w0, uint32_t n_tok, uint32_t 
         SAGE_BY_WIDTH_F32(launch_dots, c, e32, n_occ, nullptr, nullptr, SAGE_K_SCORE)
     } else {
         SAGE_BY_WIDTH_F32(launch_dots, c, e32, n_occ, c->exact_list.as<uint32_t>(), c->exact_count.as<uint32_t>(), SAGE_K_SCORE)
-        SAGE_BY_WIDTH_F64(launch_dots, c, e64, n_occ, c->inex_list.as<uint32_t>(), c->inex_count.as<uint32_t>(), SAGE_K_FIX)
+        SAGE_BY_WIDTH_F64(launch_dots_mixed, c, n_occ)
     }
     {
         Prof p(c, SAGE_K_LOGSIG);

@@ -454,6 +454,28 @@ __device__ __forceinline__ void load_row_slice(const float* __restrict__ emb, ui
         r[4 * i] = v.x; r[4 * i + 1] = v.y; r[4 * i + 2] = v.z; r[4 * i + 3] = v.w;
     }
 }
+// A float32 row loaded with the float64 slice's element mapping (lane gl, load i: elements 2*gl + 2*G*i + {0,1}) into
+// the bit storage of the first EPL/2 doubles of the slice; widen_slice() turns it into EPL doubles in place.  For
+// k_dots<double, MIXED>: the rows of an inexact occurrence's window that the float32 copy does hold.
+template <int G, int EPL>
+__device__ __forceinline__ void load_row_slice_f32_bits(const float* __restrict__ emb, uint32_t id, uint32_t dp, uint32_t gl,
+                                                        double (&r)[EPL]) {
+    const uint2* row = reinterpret_cast<const uint2*>(emb + (size_t)id * dp) + gl;
+#pragma unroll
+    for (int i = 0; i < EPL / 2; ++i) {
+        const uint2 v = row[(size_t)G * i];
+        r[i] = __hiloint2double((int)v.y, (int)v.x);
+    }
+}
+template <int EPL>
+__device__ __forceinline__ void widen_slice(double (&r)[EPL]) {
+#pragma unroll
+    for (int i = EPL / 2 - 1; i >= 0; --i) {
+        const float lo = __int_as_float(__double2loint(r[i])), hi = __int_as_float(__double2hiint(r[i]));
+        r[2 * i] = (double)lo;
+        r[2 * i + 1] = (double)hi;
+    }
+}
 // (bound_ctrl: every lane of these patterns has a source lane, and without it the compiler zeroes the destination
 // register before every DPP move)
 // Sum over the G lanes of a group, result in every lane.  The first levels are DPP moves inside a 16-lane row
@@ -570,12 +592,19 @@ __global__ __launch_bounds__(256) void k_pair_cache(const uint32_t* __restrict__
 // flight while row j is reduced, the next occurrence's header is loaded one occurrence ahead, and there is no
 // barrier, no LDS and no transcendental code in this kernel, so a CU keeps >100 KB of row gathers outstanding.
 // ----------------------------------------------------------------------------------------------------------
-template <int G, int EPL, typename T, int NS>
-__global__ __launch_bounds__(256) void k_dots(const uint4* __restrict__ desc, const uint32_t* __restrict__ pool,
+// MIXED (T = double, the float64 pass over the inexact list): only the rows marked in `bitmap` come from the float64
+// matrix; the other rows of such a window (all but one of its ~7, on average) come from the float32 copy `emb32` --
+// half the bytes -- and are widened when they become current.  The bitmap word of an id is fetched one step before
+// its row load is issued, so the choice costs no exposed latency (one more id in flight than the plain kernel).
+template <int G, int EPL, typename T, int NS, bool MIXED = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_dots(const uint4* __restrict__ desc, const uint32_t* __restrict__ pool,
                                               uint32_t n_occ, const uint32_t* __restrict__ dot_off,
                                               const T* __restrict__ emb, uint32_t emb_rows, uint32_t dp,
                                               double* __restrict__ dots, uint32_t* __restrict__ flags,
-                                              const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count) {
+                                              const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count,
+                                              const float* __restrict__ emb32 = nullptr,
+                                              const uint32_t* __restrict__ bitmap = nullptr) {
+    static_assert(!MIXED || std::is_same<T, double>::value, "MIXED is a variant of the float64 kernel");
     // list != nullptr: only the *list_count occurrences on the list are processed (float64 fix-up pass of the float32
     // fast path)
     const uint32_t gl = threadIdx.x % G;
@@ -590,7 +619,7 @@ __global__ __launch_bounds__(256) void k_dots(const uint4* __restrict__ desc, co
     // runs a queue of NI window ids whose loads are in flight, so the dependent chain id -> row address -> row never
     // stalls a step: an element enters as an id load, NI steps later its row load is issued, NF steps later it is
     // reduced against its two predecessors.
-    constexpr int NF = NS - 3, NI = SAGE_NI, NQ = NF + NI;
+    constexpr int NF = NS - 3, NI = SAGE_NI + (MIXED ? 1 : 0), NQ = NF + NI;
     static_assert(NF >= 1, "ring too short");
     T B[NS][EPL];
     // float32 storage: a row is widened to float64 once, when it becomes current, and kept that way for the two steps
@@ -633,6 +662,8 @@ __global__ __launch_bounds__(256) void k_dots(const uint4* __restrict__ desc, co
     double mydot = 0.0;
 #pragma unroll
     for (int i = 0; i < NI; ++i) fetch_id(qid[i], qm[NF + i], qo[NF + i]);
+    uint32_t bw = 0;       // MIXED: bitmap word of the id whose row load is issued next
+    if constexpr (MIXED) bw = bitmap[(qid[0] < emb_rows ? qid[0] : 0u) >> 5];
     for (;;) {
         uint32_t pending = 0;
 #pragma unroll
@@ -651,7 +682,19 @@ __global__ __launch_bounds__(256) void k_dots(const uint4* __restrict__ desc, co
             for (int i = 0; i + 1 < NI; ++i) qid[i] = qid[i + 1];
             fetch_id(qid[NI - 1], qm[NQ - 1], qo[NQ - 1]);
             if (rid >= emb_rows) { if (rlive) flags[FLAG_ROW_OOB] = 1; rid = 0; }
-            load_row_slice<G, EPL>(emb, rid, dp, gl, B[(s + NF) % NS]);
+            if constexpr (MIXED) {
+                const bool from32 = ((bw >> (rid & 31u)) & 1u) == 0u;
+                bw = bitmap[(qid[0] < emb_rows ? qid[0] : 0u) >> 5];           // for the next step's row
+                if (from32) {
+                    load_row_slice_f32_bits<G, EPL>(emb32, rid, dp, gl, B[(s + NF) % NS]);
+                    qm[NF - 1] |= 16u;                                       // bit4: the slice holds float32 bits
+                } else {
+                    load_row_slice<G, EPL>(emb, rid, dp, gl, B[(s + NF) % NS]);
+                }
+            } else {
+                load_row_slice<G, EPL>(emb, rid, dp, gl, B[(s + NF) % NS]);
+            }
+            if constexpr (MIXED) { if (m0 & 16u) widen_slice<EPL>(B[s]); }
             if constexpr (WIDEN) {
 #pragma unroll
                 for (int e = 0; e < EPL; ++e) C[s][e] = (double)B[s][e];

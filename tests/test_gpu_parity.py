@@ -175,8 +175,9 @@ def test_step_vs_oracle(style, max_len, dim):
         eng.close()
 
 
-@pytest.mark.parametrize("kind", ["f32_exact", "mixed", "f64_all"])
-def test_score_storage_modes(kind):
+@pytest.mark.parametrize("kind,dim", [("f32_exact", 50), ("mixed", 50), ("f64_all", 50), ("mixed", 20), ("mixed", 100),
+                                      ("mixed", 200), ("mixed", 300), ("mixed", 400)])
+def test_score_storage_modes(kind, dim):
     """float32 row storage (score mode 0) is lossless: exact rows are gathered from the float32 copy, every pair that
     touches another row is recomputed from the float64 matrix.  Both modes must agree with the oracle."""
     from oracle import sage_oracle as orc
@@ -185,12 +186,12 @@ def test_score_storage_modes(kind):
     corpus, off = synth.make_corpus(300, seed=77, style="en", n_types=2000, mean_log_words=2.8)
     vocab = synth.make_vocab(corpus, off, 2500, 16, sample_bytes=300_000)
     rs = np.random.RandomState(3)
-    emb = rs.normal(0.0, 0.3, size=(len(vocab), 50))
+    emb = rs.normal(0.0, 0.3, size=(len(vocab), dim))
     if kind != "f64_all":
         emb = emb.astype(np.float32).astype(np.float64)
     if kind == "mixed":
         miss = rs.random_sample(len(vocab)) < 0.1
-        emb[miss] = rs.uniform(-0.01, 0.01, size=(int(miss.sum()), 50))
+        emb[miss] = rs.uniform(-0.01, 0.01, size=(int(miss.sum()), dim))
     lines = synth.corpus_lines(corpus, off)
     tok = orc.OracleTokenizer(vocab, 16)
     occs = {}
