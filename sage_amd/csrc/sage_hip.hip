@@ -356,12 +356,12 @@ void launch_dots_mixed(sage_ctx* c, uint32_t n_occ) {
     static std::atomic<int> cached{0};
     int per_cu = cached.load(std::memory_order_relaxed);
     if (per_cu == 0) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_dots<G, EPL, double, 5, true>, 256, 0) != hipSuccess || per_cu < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_dots_mixed<G, EPL, 5>, 256, 0) != hipSuccess || per_cu < 1)
             per_cu = 4;
         cached.store(per_cu, std::memory_order_relaxed);
     }
     const uint32_t grid = std::min<uint32_t>(cdiv(n_occ, 256 / G), (uint32_t)c->n_cu * (uint32_t)std::max(per_cu, 1));
-    k_dots<G, EPL, double, 5, true><<<grid, 256, 0, c->stream>>>(
+    k_dots_mixed<G, EPL, 5><<<grid, 256, 0, c->stream>>>(
         c->desc.as<uint4>(), c->pool.as<uint32_t>(), n_occ, c->dot_off.as<uint32_t>(), c->emb.as<double>(), (uint32_t)c->emb_rows,
         (uint32_t)c->dp, c->dots.as<double>(), c->flags.as<uint32_t>(), c->inex_list.as<uint32_t>(), c->inex_count.as<uint32_t>(),
         c->emb32.as<float>(), c->inexact.as<uint32_t>());

@@ -597,7 +597,7 @@ __global__ __launch_bounds__(256) void k_pair_cache(const uint32_t* __restrict__
 // half the bytes -- and are widened when they become current.  The bitmap word of an id is fetched one step before
 // its row load is issued, so the choice costs no exposed latency (one more id in flight than the plain kernel).
 template <int G, int EPL, typename T, int NS, bool MIXED = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_dots(const uint4* __restrict__ desc, const uint32_t* __restrict__ pool,
+__device__ __forceinline__ void dots_body(const uint4* __restrict__ desc, const uint32_t* __restrict__ pool,
                                               uint32_t n_occ, const uint32_t* __restrict__ dot_off,
                                               const T* __restrict__ emb, uint32_t emb_rows, uint32_t dp,
                                               double* __restrict__ dots, uint32_t* __restrict__ flags,
@@ -722,6 +722,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
     }
     if (gl < pend) dots[wr + gl] = mydot;
+}
+
+template <int G, int EPL, typename T, int NS>
+__global__ __launch_bounds__(256) void k_dots(const uint4* __restrict__ desc, const uint32_t* __restrict__ pool,
+                                              uint32_t n_occ, const uint32_t* __restrict__ dot_off,
+                                              const T* __restrict__ emb, uint32_t emb_rows, uint32_t dp,
+                                              double* __restrict__ dots, uint32_t* __restrict__ flags,
+                                              const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count) {
+    dots_body<G, EPL, T, NS, false>(desc, pool, n_occ, dot_off, emb, emb_rows, dp, dots, flags, list, list_count, nullptr, nullptr);
+}
+// (held to 128 registers = 4 waves per SIMD: the compiler's own choice is 143 and 3 waves, which loses more than the
+// bytes saved; every float64 instantiation has EPL <= 8 and fits without spilling -- the float32 kernel for D = 300,
+// EPL = 12, does not, which is why the plain kernel carries no such attribute)
+template <int G, int EPL, int NS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_dots_mixed(const uint4* __restrict__ desc, const uint32_t* __restrict__ pool, uint32_t n_occ,
+                  const uint32_t* __restrict__ dot_off, const double* __restrict__ emb, uint32_t emb_rows, uint32_t dp,
+                  double* __restrict__ dots, uint32_t* __restrict__ flags, const uint32_t* __restrict__ list,
+                  const uint32_t* __restrict__ list_count, const float* __restrict__ emb32, const uint32_t* __restrict__ bitmap) {
+    dots_body<G, EPL, double, NS, true>(desc, pool, n_occ, dot_off, emb, emb_rows, dp, dots, flags, list, list_count, emb32, bitmap);
 }
 
 // ----------------------------------------------------------------------------------------------------------
