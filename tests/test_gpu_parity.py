@@ -288,6 +288,38 @@ def test_dense_candidates_vs_oracle():
     eng.close()
 
 
+def test_explicit_ids_and_repeated_keys_vs_oracle():
+    """A vocabulary list with a repeated key: the key keeps its LAST position as id (model.py:44-51), so ids are not
+    list positions and travel to sage_set_vocab explicitly (the device-side table build reads them per key)."""
+    from oracle import sage_oracle as orc
+    from sage_amd import SaGeTokenizer, synth
+    from sage_amd.parallel import get_engine, segment_line_bounds, sync_vocab
+    corpus, off = synth.make_corpus(200, seed=9, style="en", n_types=1500, mean_log_words=2.8)
+    vocab = synth.make_vocab(corpus, off, 1200, 12, sample_bytes=200_000)
+    multi = [k for k in vocab if len(k) >= 3][:40]
+    vocab2 = list(vocab) + multi[::2] + [vocab[300]]          # repeats: those keys move to new, larger ids
+    lines = synth.corpus_lines(corpus, off)
+    tok = orc.OracleTokenizer(vocab2, 12)
+    model = SaGeTokenizer(vocab2, 12)
+    flat, koff, ids = model.packed_key_table()
+    assert ids is not None and len(ids) < len(vocab2)
+    eng = _engine()
+    eng.set_vocab_packed(flat, koff, ids, 12)
+    eng.set_corpus(corpus, off)
+    want = [t for ln in lines for t, _, _ in tok.tokenize(ln)]
+    assert eng.tokenize(0, len(lines))[0].tolist() == want
+    emb = synth.make_embeddings(model.id_space(), 50, seed=6)
+    occs = {}
+    losses, tt, ttr, sizes = orc.run_shard(tok, lines, emb, flush=10_000, occurrences=occs)
+    eng.set_embeddings(emb)
+    loss, occ, tt2, ttr2, hist = eng.ablation_step(segment_line_bounds(len(lines), 1), vsize=model.id_space())
+    assert (tt2, ttr2) == (tt, ttr)
+    got_ids = np.nonzero(occ)[0]
+    assert got_ids.tolist() == sorted(losses)
+    np.testing.assert_allclose(loss[got_ids], [losses[int(i)] for i in got_ids], rtol=RTOL, atol=1e-9)
+    eng.close()
+
+
 def test_pool_overflow_is_redone(monkeypatch):
     """Long windows keep their ids in a pool sized from the occurrence count; when it overflows the step is redone
     with a larger pool (and every reader stays in bounds meanwhile).  SAGE_POOL_FACTOR=0 starts with the minimum."""
