@@ -415,13 +415,13 @@ void launch_score(sage_ctx* c, const uint32_t* tok_w0, uint32_t n_tok, uint32_t 
         const uint32_t grid = std::min<uint32_t>(cdiv(n_occ, LOGSIG_TILE), 256u * 8u);
         if (c->deterministic)
             k_logsig<true><<<grid, 256, 0, c->stream>>>(c->desc.as<uint4>(), c->occ_tok.as<uint32_t>(), c->occ_a.as<uint32_t>(), n_occ,
-                                                        c->dot_off.as<uint32_t>(), c->dots.as<double>(), c->gcache.as<double2>(),
+                                                        c->dot_off.as<uint32_t>(), c->dots.as<double>(), c->gcache.as<double2>(), n_tok,
                                                         c->loss.as<double>(), c->loss_fix.as<unsigned long long>(),
                                                         split ? c->inex_count.as<uint32_t>() : nullptr,
                                                         c->stats.as<unsigned long long>());
         else
             k_logsig<false><<<grid, 256, 0, c->stream>>>(c->desc.as<uint4>(), c->occ_tok.as<uint32_t>(), c->occ_a.as<uint32_t>(), n_occ,
-                                                         c->dot_off.as<uint32_t>(), c->dots.as<double>(), c->gcache.as<double2>(),
+                                                         c->dot_off.as<uint32_t>(), c->dots.as<double>(), c->gcache.as<double2>(), n_tok,
                                                          c->loss.as<double>(), nullptr,
                                                          split ? c->inex_count.as<uint32_t>() : nullptr,
                                                          c->stats.as<unsigned long long>());
@@ -812,6 +812,13 @@ void sage_destroy(sage_ctx* c) {
 extern "C" int sage_debug_match_stats(unsigned long long* out, int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_match_dbg), 16 * 8) != hipSuccess) return 1;
     if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_match_dbg), z, 16 * 8) != hipSuccess) return 1; }
+    return 0;
+}
+#endif
+#ifdef PHASE_CLOCKS
+extern "C" int sage_debug_phase_clocks(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_dbg), 32 * 8) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_dbg), z, 32 * 8) != hipSuccess) return 1; }
     return 0;
 }
 #endif

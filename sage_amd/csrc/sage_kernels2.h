@@ -41,6 +41,20 @@ __device__ __forceinline__ void acc_add_u32(uint32_t* cid, uint32_t* cval, unsig
     else atomicAdd(&global[id], 1ull);
 }
 
+#ifdef PHASE_CLOCKS
+// debug build: shader-clock stamps at the phase boundaries of k_describe<false> ([0..8]) and k_logsig<false> ([16..23])
+__device__ unsigned long long g_phase_dbg[32];
+#define PH_DECL unsigned long long ph_t = 0, ph_d[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define PH_START() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); ph_t = __builtin_amdgcn_s_memtime(); } while (0)
+#define PH_MARK(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); ph_d[i] += n_ - ph_t; ph_t = n_; } while (0)
+#define PH_FLUSH(base, n) do { if (threadIdx.x == 0) for (int i_ = 0; i_ < (n); ++i_) atomicAdd(&g_phase_dbg[(base) + i_], ph_d[i_]); } while (0)
+#else
+#define PH_DECL
+#define PH_START()
+#define PH_MARK(i)
+#define PH_FLUSH(base, n)
+#endif
+
 // ----------------------------------------------------------------------------------------------------------
 // Deterministic mode (sage_set_deterministic): every log-sigmoid term is turned into a 128-bit fixed-point number
 // (units of 2^-60) BEFORE anything is added, and all sums -- per thread, per occurrence, per workgroup, per ablated id
@@ -265,7 +279,9 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
     uint32_t* my = rows + (LONG ? 0 : threadIdx.x * DESC_LDS_STRIDE);
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t* __restrict__ bitmap = D.inexact;
+    PH_DECL;
     for (uint32_t base = blockIdx.x * 256u; base < n_round; base += gridDim.x * 256u) {
+        PH_START();
         const uint32_t item = base + threadIdx.x;
         const bool live = item < n_items;
         const uint32_t o = !live ? 0u : (LONG ? D.long_list[item] : item);
@@ -282,6 +298,7 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
             if (live) ow = load_occ_words(A, t_pre, p0_pre);
             __syncthreads();
         }
+        if (!LONG) PH_MARK(0);
         auto ldx = [&](uint32_t p) -> uint32_t {
             const uint32_t d = p - P0;
             if (!LONG && d < (uint32_t)DESC_SPAN) return span[d];
@@ -292,6 +309,7 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
         const uint32_t seg = live ? find_segment(S, t) : 0xFFFFFFFFu;
         unsigned long long my_pairs = 0;
         bool is_long = false, done = false, bad = false;
+        if (!LONG) PH_MARK(1);
         if (live) {
             uint32_t L = 0;
             Ablation w;
@@ -303,6 +321,7 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
                     return true;
                 });
                 is_long = !w.complete || w.m > SAGE_INLINE_MAX_M;
+                PH_MARK(2);
             } else {
                 w = walk_occurrence(A, t, p0, ldx, [&](uint32_t) { ++L; return true; });
             }
@@ -323,6 +342,7 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
                         }
                         bad = (acc & 1u) != 0u;
                     }
+                    PH_MARK(3);
                 } else {
                     uint32_t at = atomicAdd(D.pool_cursor, L);
                     const bool fits = at + L <= D.pool_cap && at + L >= at;
@@ -362,6 +382,7 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
             }
         }
         n_pairs += my_pairs;
+        if (!LONG) PH_MARK(4);
         {   // list appends of the tile: abandoned walks -> long list; described occurrences -> exact / inexact lists
             const bool f[3] = {is_long, done && bitmap != nullptr && !bad, done && bitmap != nullptr && bad};
             uint32_t* const lists[3] = {D.long_list, D.exact_list, D.inex_list};
@@ -380,6 +401,7 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
                 wcnt[q][4] = (tot && used) ? atomicAdd(counts[q], tot) : 0u;
             }
             __syncthreads();
+            if (!LONG) PH_MARK(5);
 #pragma unroll
             for (int q = 0; q < 3; ++q)
                 if (f[q] && (q != 0 || !LONG)) {
@@ -393,6 +415,7 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
             else atomicAdd(&D.seg_pairs[seg], my_pairs);
         }
         __syncthreads();
+        if (!LONG) PH_MARK(6);
         if (!LONG) {
             // coalesced write-out of the block's 256 descriptors (4 x 16 B each)
 #pragma unroll
@@ -405,9 +428,14 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
                 }
             }
             __syncthreads();
+            PH_MARK(7);
+#ifdef PHASE_CLOCKS
+            ph_d[8] += 1;
+#endif
         }
     }
     __syncthreads();
+    if (!LONG) PH_FLUSH(0, 9);
     if (threadIdx.x < 32 && threadIdx.x < D.hist_len && lhist[threadIdx.x])
         atomicAdd(&D.hist[threadIdx.x], (unsigned long long)lhist[threadIdx.x]);
     for (uint32_t i = threadIdx.x; i < DESC_ACC; i += 256)
@@ -750,16 +778,25 @@ void k_dots_mixed(const uint4* __restrict__ desc, const uint32_t* __restrict__ p
 // occurrence: a workgroup takes 256 consecutive occurrences, cuts their contiguous run of dots into 256 equal slices
 // (one per thread, whatever occurrence they belong to), and every thread adds its partial sums into per-occurrence
 // LDS accumulators, following the occurrence boundaries as it goes.  A second phase (one thread per occurrence) adds
-// the base window as a range sum over the pair cache and accumulates per ablated id.
+// the base window -- two index ranges of the pair cache -- and accumulates per ablated id.
+// Base spans are heavy-tailed too (a span that never rejoins runs to the end of its line), and one lane summing 100
+// entries holds its wave for 100 dependent reads: phase clocks put 35 % of the kernel there.  The tile's occurrences
+// are consecutive tokens, so the pair-cache entries of tokens t0-2 .. t0+509 (t0 = the tile's first token) are
+// loaded a tile ahead, two per thread, turned into prefix sums in LDS, and a range becomes two reads.  The prefix
+// sums of a tile stay below 512 * LOGSIG_PS_LIMIT, so a difference is off by < 1e-9 absolute; a tile that holds a
+// larger or non-finite entry, a span that leaves the staged range, and deterministic mode (which adds fixed-point
+// terms, not float64 sums) add the entries one by one instead.
 // ----------------------------------------------------------------------------------------------------------
 #define LOGSIG_TILE 256
 #define LOGSIG_PF 8      // dots of a thread's slice loaded ahead (a tile of 256 occurrences has ~8 dots per thread)
-#define LOGSIG_WIN 6     // pair-cache entries t-2 .. t+3 loaded ahead (centres of up to 4 base tokens)
+#define LOGSIG_WIN 6     // DET: pair-cache entries t-2 .. t+3 loaded ahead (centres of up to 4 base tokens)
+#define LOGSIG_GS 512    // pair-cache entries of a tile staged as prefix sums
+#define LOGSIG_PS_LIMIT 1.0e4
 template <bool DET>
 __global__ __launch_bounds__(256) void k_logsig(const uint4* __restrict__ desc, const uint32_t* __restrict__ occ_tok,
                                                 const uint32_t* __restrict__ occ_a, uint32_t n_occ,
                                                 const uint32_t* __restrict__ dot_off, const double* __restrict__ dots,
-                                                const double2* __restrict__ Gc, double* __restrict__ loss,
+                                                const double2* __restrict__ Gc, uint32_t n_tok, double* __restrict__ loss,
                                                 unsigned long long* __restrict__ loss_fix /* DET: [vsize][2] fixed-point sums */,
                                                 const uint32_t* __restrict__ inex_count, unsigned long long* __restrict__ stats) {
     // Every dot is in place when this runs: with float32 row storage k_describe has split the occurrences, the ones
@@ -772,10 +809,16 @@ __global__ __launch_bounds__(256) void k_logsig(const uint4* __restrict__ desc, 
     __shared__ uint32_t off[LOGSIG_TILE + 1];
     __shared__ unsigned long long osum0[LOGSIG_TILE];
     __shared__ unsigned long long osum1[DET ? LOGSIG_TILE : 1];
+    __shared__ double2 Ps[DET ? 1 : LOGSIG_GS + 1];                // Ps[j] = sum of the staged entries before entry j
+    __shared__ double2 wtot[4];
+    __shared__ uint32_t tile_bad[2];                               // by tile parity: the prefix sums of this tile are not to be used
     double* acc_val = reinterpret_cast<double*>(acc_w0);
     double* osum = reinterpret_cast<double*>(osum0);
     for (uint32_t i = threadIdx.x; i < ACC_SLOTS; i += 256) { acc_id[i] = ACC_EMPTY; acc_w0[i] = 0ull; if (DET) acc_w1[i] = 0ull; }
+    if (threadIdx.x < 2) tile_bad[threadIdx.x] = 0u;
     const double* Gd = reinterpret_cast<const double*>(Gc);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t stride = gridDim.x * LOGSIG_TILE;
     // DET: a term that is not finite cannot be held in fixed point; it goes into the float64 vector of its ablated id
     auto stray = [&](uint32_t o, double term) { unsafeAtomicAdd(&loss[occ_a[o] & SAGE_ID_MASK], term); };
     // the per-occurrence words of the NEXT tile are loaded while this one is processed (a first level of dependent loads
@@ -787,8 +830,25 @@ __global__ __launch_bounds__(256) void k_logsig(const uint4* __restrict__ desc, 
         if (threadIdx.x < nt) { nx_off = dot_off[o0 + threadIdx.x]; nx_a = occ_a[o0 + threadIdx.x]; nx_t = occ_tok[o0 + threadIdx.x]; }
         if (threadIdx.x == 0) nx_end = dot_off[o0 + nt];
     };
+    // !DET: so are its pair-cache entries, which takes the first token of the tile after next
+    double2 ng0 = make_double2(0.0, 0.0), ng1 = ng0;
+    uint32_t t0_staged = 0, t0_after = 0;     // first token of the tile whose entries are in ng0/ng1; of the tile after it
+    auto first_token = [&](uint32_t o0) -> uint32_t { return o0 < n_occ ? occ_tok[o0] : 0u; };
+    auto stage = [&](uint32_t t0) {
+        const long long i0 = (long long)t0 - 2 + 2 * (long long)threadIdx.x;
+        ng0 = (i0 >= 0 && i0 < (long long)n_tok) ? Gc[i0] : make_double2(0.0, 0.0);
+        ng1 = (i0 + 1 >= 0 && i0 + 1 < (long long)n_tok) ? Gc[i0 + 1] : make_double2(0.0, 0.0);
+        t0_staged = t0;
+    };
     prefetch(blockIdx.x * LOGSIG_TILE);
-    for (uint32_t o0 = blockIdx.x * LOGSIG_TILE; o0 < n_occ; o0 += gridDim.x * LOGSIG_TILE) {
+    if (!DET) {
+        stage(first_token(blockIdx.x * LOGSIG_TILE));
+        t0_after = first_token(blockIdx.x * LOGSIG_TILE + stride);
+    }
+    PH_DECL;
+    uint32_t par = 0;
+    for (uint32_t o0 = blockIdx.x * LOGSIG_TILE; o0 < n_occ; o0 += stride, par ^= 1u) {
+        PH_START();
         const uint32_t nt = min((uint32_t)LOGSIG_TILE, n_occ - o0);   // occurrences of this tile
         __syncthreads();
         if (threadIdx.x < nt) off[threadIdx.x] = nx_off;
@@ -798,10 +858,36 @@ __global__ __launch_bounds__(256) void k_logsig(const uint4* __restrict__ desc, 
         const uint32_t o = o0 + threadIdx.x;
         uint32_t t = 0, a_w0 = 0;
         if (threadIdx.x < nt) { a_w0 = nx_a; t = nx_t; }
-        prefetch(o0 + gridDim.x * LOGSIG_TILE);
+        const double2 g0 = ng0, g1 = ng1;
+        const uint32_t t0 = t0_staged;
+        prefetch(o0 + stride);
+        double2 excl = make_double2(0.0, 0.0), run = excl;
+        if (!DET) {
+            if (o0 + stride < n_occ) stage(t0_after);
+            t0_after = first_token(o0 + 2u * stride);
+            // prefix sums of this tile's entries: thread totals scanned per wave, wave totals through LDS
+            const bool big = !(fabs(g0.x) < LOGSIG_PS_LIMIT) || !(fabs(g0.y) < LOGSIG_PS_LIMIT) ||
+                             !(fabs(g1.x) < LOGSIG_PS_LIMIT) || !(fabs(g1.y) < LOGSIG_PS_LIMIT);       // NaN counts as big
+            if (big) tile_bad[par] = 1u;
+            if (threadIdx.x == 0) tile_bad[par ^ 1u] = 0u;       // last read before this tile's first barrier
+            run = make_double2(g0.x + g1.x, g0.y + g1.y);
+            const double2 own = run;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const double ux = __shfl_up(run.x, d, 64), uy = __shfl_up(run.y, d, 64);
+                if (lane >= (uint32_t)d) { run.x += ux; run.y += uy; }
+            }
+            if (lane == 63u) wtot[wave] = run;
+            excl = make_double2(run.x - own.x, run.y - own.y);
+        }
         __syncthreads();
-        // ---- loads of both phases issued together: the pair-cache window of this thread's occurrence (phase 2), the
-        // ablated id, and the first LOGSIG_PF dots of this thread's slice (phase 1) -- one exposed latency per tile
+        PH_MARK(0);
+        if (!DET) {
+            for (uint32_t w = 0; w < wave; ++w) { excl.x += wtot[w].x; excl.y += wtot[w].y; }
+            if (threadIdx.x == 0) Ps[0] = make_double2(0.0, 0.0);
+            Ps[2u * threadIdx.x + 1u] = make_double2(excl.x + g0.x, excl.y + g0.y);
+            Ps[2u * threadIdx.x + 2u] = make_double2(excl.x + g0.x + g1.x, excl.y + g0.y + g1.y);     // read after the next barrier
+        }
         // pads and base-span length ride in the ablated-id word: the 64-byte descriptor is read only for a span of
         // 127 tokens or more (a strided 16-byte read per occurrence otherwise: 4x its bytes in lines)
         Win w;
@@ -814,24 +900,10 @@ __global__ __launch_bounds__(256) void k_logsig(const uint4* __restrict__ desc, 
         const int lo1 = ipl >= 1 ? -1 : 0, hi1 = im - 2 + (ipr >= 1 ? 1 : 0);
         const int lo2 = -ipl, hi2 = im + ipr - 3;
         const bool live = threadIdx.x < nt;
-        const bool small = im <= LOGSIG_WIN - 2;     // rel in [-2, LOGSIG_WIN - 3] covers every term
-        double2 W[LOGSIG_WIN];
-        if (live) {
-            if (small) {
-#pragma unroll
-                for (int q = 0; q < LOGSIG_WIN; ++q) {
-                    const int rel = q - 2;
-                    W[q] = (rel >= min(lo1, lo2) && rel <= max(hi1, hi2)) ? Gc[(size_t)t + rel] : make_double2(0.0, 0.0);
-                }
-            }
-        }
         const uint32_t d0 = off[0], d1 = off[nt];
         const uint32_t per = (d1 - d0 + 255u) / 256u;
         uint32_t i = d0 + threadIdx.x * per;
         const uint32_t iend = min(d1, i + per);
-        double v[LOGSIG_PF];
-#pragma unroll
-        for (int q = 0; q < LOGSIG_PF; ++q) v[q] = (i + q < iend) ? dots[i + q] : 0.0;
         // base-window sum of this thread's occurrence: a float64 sum, or (DET) a fixed-point sum of its terms
         double sb = 0.0;
         Fix128 sbf{0ull, 0};
@@ -839,22 +911,46 @@ __global__ __launch_bounds__(256) void k_logsig(const uint4* __restrict__ desc, 
             if (!DET) { sb += g; return; }
             if (fabs(g) < FIX_LIMIT) fix_add(sbf, fix_from(g)); else stray(o, 2.0 * g);
         };
-        if (live) {
-            if (small) {
-#pragma unroll
-                for (int q = 1; q < LOGSIG_WIN; ++q) { const int rel = q - 2; if (rel >= lo1 && rel <= hi1) base_term(W[q].x); }
+        auto base_terms_one_by_one = [&]() {
+            for (int rel = lo1; rel <= hi1; ++rel) base_term(Gd[((size_t)t + rel) * 2]);
+            for (int rel = lo2; rel <= hi2; ++rel)
+                if ((rel >= 0 && rel <= im - 1) || (rel + 2 >= 0 && rel + 2 <= im - 1)) base_term(Gd[((size_t)t + rel) * 2 + 1]);
+        };
+        double v[LOGSIG_PF];
+        if constexpr (DET) {
+            // loads of both phases issued together: the pair-cache window of this thread's occurrence and the first
+            // LOGSIG_PF dots of this thread's slice -- one exposed latency per tile
+            const bool small = im <= LOGSIG_WIN - 2;     // rel in [-2, LOGSIG_WIN - 3] covers every term
+            double2 W[LOGSIG_WIN];
+            if (live && small) {
 #pragma unroll
                 for (int q = 0; q < LOGSIG_WIN; ++q) {
                     const int rel = q - 2;
-                    const bool in = rel >= lo2 && rel <= hi2 && ((rel >= 0 && rel <= im - 1) || (rel + 2 >= 0 && rel + 2 <= im - 1));
-                    if (in) base_term(W[q].y);
+                    W[q] = (rel >= min(lo1, lo2) && rel <= max(hi1, hi2)) ? Gc[(size_t)t + rel] : make_double2(0.0, 0.0);
                 }
-            } else {
-                for (int rel = lo1; rel <= hi1; ++rel) base_term(Gd[((size_t)t + rel) * 2]);
-                for (int rel = lo2; rel <= hi2; ++rel)
-                    if ((rel >= 0 && rel <= im - 1) || (rel + 2 >= 0 && rel + 2 <= im - 1)) base_term(Gd[((size_t)t + rel) * 2 + 1]);
             }
+#pragma unroll
+            for (int q = 0; q < LOGSIG_PF; ++q) v[q] = (i + q < iend) ? dots[i + q] : 0.0;
+            if (live) {
+                if (small) {
+#pragma unroll
+                    for (int q = 1; q < LOGSIG_WIN; ++q) { const int rel = q - 2; if (rel >= lo1 && rel <= hi1) base_term(W[q].x); }
+#pragma unroll
+                    for (int q = 0; q < LOGSIG_WIN; ++q) {
+                        const int rel = q - 2;
+                        const bool in = rel >= lo2 && rel <= hi2 && ((rel >= 0 && rel <= im - 1) || (rel + 2 >= 0 && rel + 2 <= im - 1));
+                        if (in) base_term(W[q].y);
+                    }
+                } else {
+                    base_terms_one_by_one();
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < LOGSIG_PF; ++q) v[q] = (i + q < iend) ? dots[i + q] : 0.0;
         }
+        PH_MARK(1);
+        PH_MARK(2);
         if (i < iend) {
             // owner of dot i: largest j with off[j] <= i
             uint32_t lo = 0, hi = nt;
@@ -863,6 +959,7 @@ __global__ __launch_bounds__(256) void k_logsig(const uint4* __restrict__ desc, 
                 if (off[mid] <= i) lo = mid; else hi = mid;
             }
             uint32_t own = lo, nxt = off[own + 1];
+            PH_MARK(3);
             double acc = 0.0;
             Fix128 accf{0ull, 0};
             auto hand_over = [&]() {
@@ -891,9 +988,27 @@ __global__ __launch_bounds__(256) void k_logsig(const uint4* __restrict__ desc, 
             }
             hand_over();
         }
+        PH_MARK(4);
         __syncthreads();
+        PH_MARK(5);
         if (live) {
             if (!DET) {
+                // the base window from the tile's prefix sums: Ps index of rel = 0 is t - t0 + 2
+                const uint32_t dj = t - t0;                                     // (wraps to a large value should t < t0)
+                const int top = max(max(hi1, hi2), 0);
+                const bool staged = tile_bad[par] == 0u && dj < (uint32_t)LOGSIG_GS && (long long)dj + 2 + top + 1 <= (long long)LOGSIG_GS;
+                if (staged) {
+                    const int j0 = (int)dj + 2;
+                    sb = Ps[j0 + hi1 + 1].x - Ps[j0 + lo1].x;                    // (an empty range has hi1 = lo1 - 1)
+                    if (im >= 2) {
+                        sb += Ps[j0 + hi2 + 1].y - Ps[j0 + lo2].y;               // rel in [lo2, hi2], all of it counted
+                    } else {                                                    // m == 1: rel = -2 and rel = 0 only
+                        if (ipl == 2) sb += Ps[j0 - 1].y - Ps[j0 - 2].y;
+                        if (ipr == 2) sb += Ps[j0 + 1].y - Ps[j0].y;
+                    }
+                } else {
+                    base_terms_one_by_one();
+                }
                 acc_add_f64(acc_id, acc_val, loss, SAGE_T_ID(a_w0), -2.0 * (osum[threadIdx.x] - sb));
             } else {      // -2 * (ablated - base) = 2 * (base - ablated), all in fixed point
                 Fix128 tot = sbf;
@@ -901,7 +1016,12 @@ __global__ __launch_bounds__(256) void k_logsig(const uint4* __restrict__ desc, 
                 acc_add_fix(acc_id, acc_w0, acc_w1, loss_fix, SAGE_T_ID(a_w0), fix_twice(tot));
             }
         }
+        PH_MARK(6);
+#ifdef PHASE_CLOCKS
+        ph_d[7] += 1;
+#endif
     }
+    if (!DET) PH_FLUSH(16, 8);
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < ACC_SLOTS; i += 256)
         if (acc_id[i] != ACC_EMPTY) {
