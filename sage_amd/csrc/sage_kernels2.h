@@ -42,8 +42,8 @@ __device__ __forceinline__ void acc_add_u32(uint32_t* cid, uint32_t* cval, unsig
 }
 
 #ifdef PHASE_CLOCKS
-// debug build: shader-clock stamps at the phase boundaries of k_describe<false> ([0..8]) and k_logsig<false> ([16..23])
-__device__ unsigned long long g_phase_dbg[32];
+// debug build: shader-clock stamps at the phase boundaries of k_describe<false> ([0..8]) and k_logsig<false> ([16..23]), k_key_partition3<1> ([32..40])
+__device__ unsigned long long g_phase_dbg[48];
 #define PH_DECL unsigned long long ph_t = 0, ph_d[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define PH_START() do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); ph_t = __builtin_amdgcn_s_memtime(); } while (0)
 #define PH_MARK(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); ph_d[i] += n_ - ph_t; ph_t = n_; } while (0)

@@ -242,6 +242,73 @@ def test_long_windows_vs_oracle():
     eng.close()
 
 
+def test_base_spans_longer_than_a_tile_vs_oracle():
+    """Ablations that never rejoin in a line of 800 tokens: base spans of up to 800 tokens.  k_logsig sums a base window
+    from the prefix sums of the 512 pair-cache entries staged per tile; these spans leave that range and are added
+    entry by entry, in the same tiles as spans that stay inside it."""
+    from oracle import sage_oracle as orc
+    from sage_amd import synth
+    from sage_amd.parallel import pack_lines, segment_line_bounds
+    vocab = [bytes([i]) for i in range(256)] + [b"ab", b"ba", b"the ", b" cat", b"abab"]
+    lines = [b"the cat " + b"ab" * 150 + b"\n", b"ba" * 3 + b"ab" * 1600, b"the cat the cat\n", b"xab" * 40 + b"\n"] * 2
+    emb = synth.make_embeddings(len(vocab), 20, seed=4)
+    tok = orc.OracleTokenizer(vocab, 4)
+    occs = {}
+    losses, tt, ttr, sizes = orc.run_shard(tok, lines, emb, flush=10_000, occurrences=occs)
+    assert max(sizes) > 700
+    eng = _engine()
+    eng.set_vocab(vocab, None, 4)
+    flat, off = pack_lines(lines)
+    eng.set_corpus(flat, off)
+    eng.set_embeddings(emb)
+    _check_step(eng, segment_line_bounds(len(lines), 1), tt, ttr, losses, sizes, want_occ=occs)
+    eng.set_deterministic(True)
+    _check_step_once(eng, segment_line_bounds(len(lines), 1), tt, ttr, losses, sizes, want_occ=occs)
+    eng.close()
+
+
+@pytest.mark.parametrize("storage", ["f32", "f64"])
+def test_nan_row_reaches_only_its_own_ids(storage):
+    """A NaN in the caller's embeddings: the reference's loss is NaN for exactly the ablated ids that have an occurrence
+    whose ablated or base window touches that row, and finite for every other id.  (k_logsig's per-tile prefix sums must
+    not spread it: a tile that holds a non-finite pair-cache entry is summed entry by entry.)"""
+    from oracle import sage_oracle as orc
+    from sage_amd import synth
+    from sage_amd.parallel import segment_line_bounds
+    corpus, off = synth.make_corpus(300, seed=78, style="en", n_types=2000, mean_log_words=2.8)
+    vocab = synth.make_vocab(corpus, off, 2500, 16, sample_bytes=300_000)
+    rs = np.random.RandomState(5)
+    emb = rs.normal(0.0, 0.3, size=(len(vocab), 50))
+    if storage == "f32":
+        emb = emb.astype(np.float32).astype(np.float64)
+    lines = synth.corpus_lines(corpus, off)
+    tok = orc.OracleTokenizer(vocab, 16)
+    eng = _engine()
+    eng.set_vocab(vocab, None, 16)
+    eng.set_corpus(corpus, off)
+    counts = np.bincount(eng.tokenize(0, len(lines))[0], minlength=len(vocab))
+    multi = np.array([len(k) > 1 for k in vocab])
+    order = np.argsort(-(counts * multi))
+    emb[order[40]] = np.nan          # a multi-byte token with a few dozen occurrences
+    with np.errstate(all="ignore"):
+        losses, tt, ttr, sizes = orc.run_shard(tok, lines, emb, flush=10_000)
+    want_nan = {k for k, v in losses.items() if np.isnan(v)}
+    assert 0 < len(want_nan) < len(losses) // 2
+    eng.set_embeddings(emb)
+    for det in (False, True):
+        eng.set_deterministic(det)
+        loss, occ, tt2, ttr2, hist = eng.ablation_step(segment_line_bounds(len(lines), 1))
+        assert (tt2, ttr2) == (tt, ttr)
+        ids = np.nonzero(occ)[0]
+        assert ids.tolist() == sorted(losses)
+        got_nan = {int(i) for i in ids if np.isnan(loss[i])}
+        assert got_nan == want_nan, (det, sorted(got_nan ^ want_nan)[:10])
+        fin = [int(i) for i in ids if int(i) not in want_nan]
+        want = np.array([losses[i] for i in fin])
+        np.testing.assert_allclose(loss[fin], want, rtol=RTOL, atol=1e-9 * float(np.abs(want).max()))
+    eng.close()
+
+
 def test_dense_candidates_vs_oracle():
     """Text in which EVERY position has a key of every length (runs of one letter, all of whose powers are keys): a
     64-byte tile then holds 64 x 8 candidates in the long class and 64 x 4 in the middle one, more than the matcher's

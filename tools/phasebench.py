@@ -17,7 +17,7 @@ e.set_embeddings(emb)
 b = segment_line_bounds(N, 4)
 for _ in range(2): e.ablation_step(b)
 lib = C.CDLL(str(_lib.LIB_PATH))
-out = (C.c_ulonglong * 32)()
+out = (C.c_ulonglong * 48)()
 lib.sage_debug_phase_clocks(out, 1)
 e.ablation_step(b)
 lib.sage_debug_phase_clocks(out, 0)
@@ -28,6 +28,7 @@ def show(name, base, labels, ntile_idx):
     print(name, "tiles (thread 0's)", tiles, "clocks per tile", round(tot / max(tiles, 1)))
     for l, x in zip(labels, v):
         print(f"   {l:34s} {x / max(tiles, 1):9.0f}  {100.0 * x / max(tot, 1):5.1f} %")
+show("k_key_partition3<1>", 32, ["clear + tile set-up", "phase A (inline occurrences)", "barrier", "pooled A + barrier", "scan + reservations", "phase B (inline)", "pooled B + barrier", "copy-out"], 8)
 show("k_describe<false>", 0, ["loads + span + barrier", "segment search", "walk", "bitmap", "outputs + atomics", "list ballots + barriers + atomic",
                               "list stores + seg atomics + barrier", "descriptor write-out + barrier"], 8)
 show("k_logsig<false>", 16, ["tile set-up + 2 barriers", "loads (G window, dots)", "base sum", "owner search", "dot loop", "barrier", "accumulate"], 7)
