@@ -866,6 +866,15 @@ __device__ __forceinline__ uint32_t set_insert(unsigned long long* __restrict__ 
 // ----------------------------------------------------------------------------------------------------------
 // log(sigmoid(x)) in float64 (utils.py:136)
 // ----------------------------------------------------------------------------------------------------------
+// The polynomial coefficients are read from constant memory: uniform loads, so they sit in SGPRs and feed v_fma_f64 as
+// its scalar operand.  As literals every Horner step costs two v_mov_b32 for the coefficient on top of its fma
+// (108 VALU instructions per evaluation, 39 of them moves; 70 this way), and k_logsig's dot loop is VALU-bound.
+__constant__ double LS_C[24] = {
+    1.0 / 6227020800.0, 1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0, 1.0 / 5040.0,
+    1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0,                                                  // exp: r^13 .. r^3
+    1.0 / 23.0, 1.0 / 21.0, 1.0 / 19.0, 1.0 / 17.0, 1.0 / 15.0, 1.0 / 13.0, 1.0 / 11.0, 1.0 / 9.0, 1.0 / 7.0, 1.0 / 5.0,
+    1.0 / 3.0,                                                                                        // atanh: s^22 .. s^2
+    -6.93147180369123816490e-01, -1.90821492927058770002e-10};                                        // -ln2, high and low
 __device__ __forceinline__ double log_sigmoid(double x) {
     // log(expit(x)) of utils.py:136 in its overflow-free form min(x,0) - log1p(exp(-|x|)), with both functions written
     // out (the library's exp and log1p carry special-case paths and ~2x the instructions; k_logsig and k_pair_cache are
@@ -875,19 +884,11 @@ __device__ __forceinline__ double log_sigmoid(double x) {
     t = t < -750.0 ? -750.0 : t;                                   // exp underflows to 0 below (NaN passes through)
     // u = exp(t) = 2^n * exp(r), |r| <= ln2/2
     const double n = rint(t * 1.4426950408889634);
-    double r = fma(n, -6.93147180369123816490e-01, t);
-    r = fma(n, -1.90821492927058770002e-10, r);
-    double p = 1.0 / 6227020800.0;
-    p = fma(p, r, 1.0 / 479001600.0);
-    p = fma(p, r, 1.0 / 39916800.0);
-    p = fma(p, r, 1.0 / 3628800.0);
-    p = fma(p, r, 1.0 / 362880.0);
-    p = fma(p, r, 1.0 / 40320.0);
-    p = fma(p, r, 1.0 / 5040.0);
-    p = fma(p, r, 1.0 / 720.0);
-    p = fma(p, r, 1.0 / 120.0);
-    p = fma(p, r, 1.0 / 24.0);
-    p = fma(p, r, 1.0 / 6.0);
+    double r = fma(n, LS_C[22], t);
+    r = fma(n, LS_C[23], r);
+    double p = LS_C[0];
+#pragma unroll
+    for (int i = 1; i <= 10; ++i) p = fma(p, r, LS_C[i]);
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
@@ -904,17 +905,9 @@ __device__ __forceinline__ double log_sigmoid(double x) {
     double s = f * y;
     s = fma(fma(-s, d, f), y, s);
     const double s2 = s * s;
-    double q = 1.0 / 23.0;
-    q = fma(q, s2, 1.0 / 21.0);
-    q = fma(q, s2, 1.0 / 19.0);
-    q = fma(q, s2, 1.0 / 17.0);
-    q = fma(q, s2, 1.0 / 15.0);
-    q = fma(q, s2, 1.0 / 13.0);
-    q = fma(q, s2, 1.0 / 11.0);
-    q = fma(q, s2, 1.0 / 9.0);
-    q = fma(q, s2, 1.0 / 7.0);
-    q = fma(q, s2, 1.0 / 5.0);
-    q = fma(q, s2, 1.0 / 3.0);
+    double q = LS_C[11];
+#pragma unroll
+    for (int i = 12; i <= 21; ++i) q = fma(q, s2, LS_C[i]);
     double lg = fma(2.0 * s * s2, q, 2.0 * s);
     lg = lg + (big ? 6.93147180559945286227e-01 : 0.0);
     lg = lg + (big ? 0.5 * e : e);
