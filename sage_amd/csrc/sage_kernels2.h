@@ -618,7 +618,8 @@ __global__ __launch_bounds__(256) void k_pair_cache(const uint32_t* __restrict__
 // do_triples counts (model.py:129-136), written back to back at dot_off[o].  Gather-bound: G lanes own one
 // occurrence and walk a continuous stream of rows across occurrence boundaries -- row j+2 and j+1 are always in
 // flight while row j is reduced, the next occurrence's header is loaded one occurrence ahead, and there is no
-// barrier, no LDS and no transcendental code in this kernel, so a CU keeps >100 KB of row gathers outstanding.
+// barrier in the loop, no LDS beyond one counter and no transcendental code in this kernel, so a CU keeps >100 KB of
+// row gathers outstanding.
 // ----------------------------------------------------------------------------------------------------------
 // MIXED (T = double, the float64 pass over the inexact list): only the rows marked in `bitmap` come from the float64
 // matrix; the other rows of such a window (all but one of its ~7, on average) come from the float32 copy `emb32` --
@@ -636,8 +637,6 @@ __device__ __forceinline__ void dots_body(const uint4* __restrict__ desc, const 
     // list != nullptr: only the *list_count occurrences on the list are processed (float64 fix-up pass of the float32
     // fast path)
     const uint32_t gl = threadIdx.x % G;
-    const uint32_t n_groups = gridDim.x * (256u / G);
-    const uint32_t gid = blockIdx.x * (256u / G) + threadIdx.x / G;
     const uint32_t n = list ? *list_count : n_occ;
     // Each element travelling through the pipeline carries: its row slice and a meta word
     //   bit0: dot with the previous element, bit1: dot with the one before, bit2: first element of an occurrence,
@@ -662,20 +661,39 @@ __device__ __forceinline__ void dots_body(const uint4* __restrict__ desc, const 
     for (int i = 0; i < NI; ++i) qid[i] = 0;
     // id side: fi = position (in the list, or plain index) of the next occurrence to open, foi = its index,
     // nh = its header words (prefetched one occurrence ahead)
-    uint32_t fi = gid, foi = 0, fj = 0, fL = 0, fpl = 0, fk = 0;
+    // Occurrences are handed out in windows of 256/G consecutive ones, the windows round-robin over the workgroups (the
+    // chip as a whole reads one moving window of descriptors, offsets and dots), and inside its window a workgroup's
+    // groups draw the next occurrence from an LDS counter as they finish: 22.9 -> 21.8 ms against a fixed round-robin
+    // over all groups of the grid, whose groups drift apart as window lengths differ.  Larger windows (4x, 16x) change
+    // nothing; a contiguous run per group (32k separate streams of descriptors, offsets and dots) took 40 ms and a
+    // contiguous run per workgroup 36 ms.
+    __shared__ uint32_t next_occ;
+    if (threadIdx.x == 0) next_occ = 0u;
+    __syncthreads();
+    constexpr uint32_t DOTS_WIN = 256u / G;
+    const uint32_t fend = n;
+    uint32_t fi = 0, foi = 0, fj = 0, fL = 0, fpl = 0, fk = 0;
+    auto next_index = [&]() {
+        uint32_t tk = 0;
+        if (gl == 0u) tk = atomicAdd(&next_occ, 1u);
+        tk = __shfl(tk, (int)((threadIdx.x & 63u) & ~(uint32_t)(G - 1)), 64);       // (the group's lanes branch together)
+        const unsigned long long at = ((unsigned long long)(tk / DOTS_WIN) * gridDim.x + blockIdx.x) * DOTS_WIN + tk % DOTS_WIN;
+        fi = at < (unsigned long long)n ? (uint32_t)at : n;
+    };
+    next_index();
     const uint32_t* fids = nullptr;
     uint4 nh = make_uint4(0, 0, 0, 0);
-    if (fi < n) { foi = list ? list[fi] : fi; nh = desc[(size_t)foi * 4]; }
+    if (fi < fend) { foi = list ? list[fi] : fi; nh = desc[(size_t)foi * 4]; }
     auto fetch_id = [&](uint32_t& id, uint32_t& meta, uint32_t& out) {
         meta = 0; id = 0;
         if (fj == fL) {   // open the next occurrence from the prefetched header, prefetch the one after
-            if (fi >= n) return;
+            if (fi >= fend) return;
             const Win w = win_decode(nh.x, nh.z, nh.w);
             fL = w.L; fpl = w.pl; fk = w.k; fj = 0;
             fids = w.pooled ? pool + nh.y : reinterpret_cast<const uint32_t*>(desc + (size_t)foi * 4) + 1;
             out = dot_off[foi];
-            fi += n_groups;
-            if (fi < n) { foi = list ? list[fi] : fi; nh = desc[(size_t)foi * 4]; }
+            next_index();
+            if (fi < fend) { foi = list ? list[fi] : fi; nh = desc[(size_t)foi * 4]; }
         }
         id = fids[fj];
         // element fj is in the centre [pl, pl+k) iff (fj - pl) < k unsigned; the same for its two predecessors
