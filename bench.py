@@ -41,7 +41,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 CLASS_KERNEL = {"match": "k_match_lds", "score": "k_dots", "count": "k_key_dedupe", "partition": "k_key_partition3",
                 "describe": "k_describe<false>", "pairs": "k_pair_cache", "logsig": "k_logsig", "walk": "k_walk_write"}
 # what bounds each kernel class (Kernels): only the "hbm" ones stream HBM; the HBM peak is quoted for all
-CLASS_BOUND = {"match": "l2-miss-traffic", "score": "l2-fabric-gather", "pairs": "l2-fabric-gather", "fix": "l2-fabric-gather",
+CLASS_BOUND = {"match": "l2-miss-traffic", "score": "row-gather-latency", "pairs": "l2-fabric-gather", "fix": "row-gather-latency",
                "count": "hbm", "partition": "hbm", "describe": "lds-latency", "logsig": "hbm", "walk": "latency"}
 
 
@@ -79,8 +79,10 @@ def roofline_object(dom, achieved, avg_ms, launches_per_step, per_kernel_bytes, 
            "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step,
            "algorithmic_bytes_per_launch": per_kernel_bytes[dom] / launches_per_step, "elem_bytes": eb,
            "note": "peak is HBM's 8 TB/s for every kernel; `frac` uses algorithmic bytes, `traffic_frac` the measured "
-                   "L2-miss-side bytes (FETCH_SIZE x 2 + WRITE_SIZE) over the same launch time: score and match pull "
-                   "5-7 TB/s through the fabric, which is what bounds them (DESIGN.md, Kernels)"}
+                   "L2-miss-side bytes (FETCH_SIZE x 2 + WRITE_SIZE) over the same launch time.  The score kernel hands "
+                   "its lanes ~6 TB/s of embedding rows, a third of them from L1/L2 (pad rows shared by consecutive "
+                   "occurrences), the rest through the fabric: bound by gather latency at 4 waves per SIMD; pairs and "
+                   "match pull 6-7 TB/s through the fabric (DESIGN.md, Kernels)"}
     if traffic and avg_ms:
         out["traffic_GBs"] = traffic["fetch_x2"] / 1e9 / (avg_ms * 1e-3)
         out["traffic_frac"] = out["traffic_GBs"] / HBM_PEAK_GBS

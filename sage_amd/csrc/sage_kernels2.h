@@ -661,16 +661,17 @@ __device__ __forceinline__ void dots_body(const uint4* __restrict__ desc, const 
     for (int i = 0; i < NI; ++i) qid[i] = 0;
     // id side: fi = position (in the list, or plain index) of the next occurrence to open, foi = its index,
     // nh = its header words (prefetched one occurrence ahead)
-    // Occurrences are handed out in windows of 256/G consecutive ones, the windows round-robin over the workgroups (the
+    // Occurrences are handed out in windows of 32 consecutive ones, the windows round-robin over the workgroups (the
     // chip as a whole reads one moving window of descriptors, offsets and dots), and inside its window a workgroup's
     // groups draw the next occurrence from an LDS counter as they finish: 22.9 -> 21.8 ms against a fixed round-robin
-    // over all groups of the grid, whose groups drift apart as window lengths differ.  Larger windows (4x, 16x) change
+    // over all groups of the grid, whose groups drift apart as window lengths differ, and 289 -> 198 ms at D = 300, where
+    // a re-read row is 1.2 KB (windows of 32 rather than one per group there: another 1.7 %).  Larger windows change
     // nothing; a contiguous run per group (32k separate streams of descriptors, offsets and dots) took 40 ms and a
     // contiguous run per workgroup 36 ms.
     __shared__ uint32_t next_occ;
     if (threadIdx.x == 0) next_occ = 0u;
     __syncthreads();
-    constexpr uint32_t DOTS_WIN = 256u / G;
+    constexpr uint32_t DOTS_WIN = 256u / G < 32u ? 32u : 256u / G;
     const uint32_t fend = n;
     uint32_t fi = 0, foi = 0, fj = 0, fL = 0, fpl = 0, fk = 0;
     auto next_index = [&]() {

@@ -1,4 +1,4 @@
-"""Per-kernel times of the ablation step on 300k lines of the bench corpus (quick A/B runs; SAGE_LIB=path picks another build)."""
+"""Per-kernel times of the ablation step on 300k lines of the bench corpus (quick A/B runs; SAGE_LIB=path picks another build, SB_LINES / SB_DIM the size)."""
 import os, pathlib, sys, numpy as np
 sys.path.insert(0, '/root/repo')
 from sage_amd import _lib, synth
@@ -12,7 +12,7 @@ vocab = synth.make_vocab(head, ho, 262144, 16, sample_bytes=6_000_000)
 corpus, off = synth.make_corpus(N, seed=seed, style="en", n_types=1_000_000)
 e = HipSage(0); e.set_vocab(vocab, None, 16); e.set_corpus(corpus, off)
 counts = np.bincount(e.tokenize(0, N)[0], minlength=len(vocab))
-emb = synth.make_embeddings(len(vocab), 50, seed=seed, unseen=~(counts > 0))
+emb = synth.make_embeddings(len(vocab), int(os.environ.get('SB_DIM', '50')), seed=seed, unseen=~(counts > 0))
 e.set_embeddings(emb)
 b = segment_line_bounds(N, 4)
 for _ in range(3): r = e.ablation_step(b)     # warm-up: the first steps on a fresh box run at ramping clocks
