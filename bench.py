@@ -189,7 +189,7 @@ def main():
         corpus, offsets = head, head_off
     else:
         log(f"vocabulary of {len(vocab)} keys built; generating {args.lines} lines")
-        corpus, offsets = synth.make_corpus(args.lines, seed=seed + rank, style=args.style, n_types=n_types,
+        corpus, offsets = synth.make_corpus(args.lines, seed=seed, line_seed=rank, style=args.style, n_types=n_types,
                                             progress=log)
     log(f"corpus: {len(corpus)} bytes")
     gen_s = time.time() - t_gen

@@ -101,6 +101,11 @@ struct sage_ctx {
     DevBuf ex_ids, ex_starts, ex_widths;
     DevBuf loss, occ, hist, stats, flags;
     DevBuf loss_fix;              // deterministic mode: 128-bit fixed-point loss sums, two words per id
+    // host tables on their way to the device: an asynchronous copy from pageable memory may still be reading its source
+    // when the call returns, so the source lives here until the step's next stream synchronisation (a std::vector
+    // local to the batch loop is unmapped at the end of its block -- seen as garbage bucket offsets)
+    std::vector<std::vector<uint32_t>> keep32;
+    std::vector<std::vector<uint64_t>> keep64;
     bool deterministic = false;
     uint64_t pair_limit = 0xFFFFFF00ull;   // 32-bit pair / dot offsets per batch (SAGE_TEST_PAIR_LIMIT lowers it: test hook)
     int64_t batch_bytes = 512ll << 20;   // fewer, larger batches: the line walks last as long as a batch's longest line (4.9 -> 3.9 ms from two batches to one)
@@ -320,6 +325,16 @@ int padded_dim(int dim) {
 }
 
 // G x EPL = lanes per row x elements per lane
+// asynchronous host-to-device copy of a small table whose source outlives the call (see sage_ctx::keep32)
+static hipError_t h2d_keep(sage_ctx* c, void* dst, const std::vector<uint32_t>& v, size_t n) {
+    c->keep32.push_back(v);
+    return hipMemcpyAsync(dst, c->keep32.back().data(), n * 4, hipMemcpyHostToDevice, c->stream);
+}
+static hipError_t h2d_keep(sage_ctx* c, void* dst, const std::vector<uint64_t>& v, size_t n) {
+    c->keep64.push_back(v);
+    return hipMemcpyAsync(dst, c->keep64.back().data(), n * 8, hipMemcpyHostToDevice, c->stream);
+}
+
 template <int G, int EPL, typename T>
 void launch_pairs(sage_ctx* c, const T* emb, const uint32_t* tok_w0, uint32_t n_tok, bool fix) {
     Prof p(c, fix ? SAGE_K_FIX : SAGE_K_PAIRS);
@@ -476,7 +491,7 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
             for (uint32_t s = 0; s <= nsb; ++s) rel[s] = (uint32_t)(bounds[sa + s] - line0);
             if ((rc = ensure(c, c->seg_line_rel, (size_t)(nsb + 1) * 4))) return rc;
             if ((rc = ensure(c, c->seg_tok_off, (size_t)(nsb + 1) * 4))) return rc;
-            HIP_TRY(c, hipMemcpyAsync(c->seg_line_rel.p, rel.data(), (size_t)(nsb + 1) * 4, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, h2d_keep(c, c->seg_line_rel.p, rel, (size_t)nsb + 1));
             k_gather_u32<<<cdiv(nsb + 1, 256), 256, 0, c->stream>>>(c->tokoff.as<uint32_t>(), c->seg_line_rel.as<uint32_t>(),
                                                                     nsb + 1, c->seg_tok_off.as<uint32_t>());
             uint64_t gt[2] = {0, 0};
@@ -593,8 +608,8 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
                 if ((rc = ensure(c, c->tile_tab, (size_t)max_tiles * 16))) return rc;
                 if ((rc = ensure(c, c->cursor, (size_t)std::max(nbk_total, 1u) * 4))) return rc;
                 if ((rc = ensure(c, c->bucket_off, ((size_t)nbk_total + 1) * 8))) return rc;
-                HIP_TRY(c, hipMemcpyAsync(c->seg_bucket_base.p, bbase.data(), (size_t)(nsb + 1) * 4, hipMemcpyHostToDevice, c->stream));
-                HIP_TRY(c, hipMemcpyAsync(c->seg_nbk_mask.p, bmask.data(), (size_t)nsb * 4, hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(c, h2d_keep(c, c->seg_bucket_base.p, bbase, (size_t)nsb + 1));
+                HIP_TRY(c, h2d_keep(c, c->seg_nbk_mask.p, bmask, (size_t)nsb));
                 PartPlan PP{c->pair_off.as<uint32_t>(), c->seg_first_occ.as<uint32_t>(), c->seg_tile_off.as<uint32_t>(),
                             c->seg_bucket_base.as<uint32_t>(), c->seg_nbk_mask.as<uint32_t>(),
                             c->bucket_off.as<unsigned long long>(), nsb};
@@ -642,7 +657,7 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
                 }
                 boff[nbk_total] = total;
                 if ((rc = ensure(c, c->rec_a, std::max<uint64_t>(total, 1) * 8))) return rc;
-                HIP_TRY(c, hipMemcpyAsync(c->bucket_off.p, boff.data(), ((size_t)nbk_total + 1) * 8, hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(c, h2d_keep(c, c->bucket_off.p, boff, (size_t)nbk_total + 1));
                 HIP_TRY(c, hipMemsetAsync(c->cursor.p, 0, (size_t)std::max(nbk_total, 1u) * 4, c->stream));
                 {
                     Prof p(c, SAGE_K_PARTITION);
@@ -679,8 +694,8 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
                     sbase[s] = slots; smask[s] = cap - 1; slots += cap;
                 }
                 if ((rc = ensure(c, c->set, slots * 8))) return rc;
-                HIP_TRY(c, hipMemcpyAsync(c->set_base.p, sbase.data(), (size_t)nsb * 8, hipMemcpyHostToDevice, c->stream));
-                HIP_TRY(c, hipMemcpyAsync(c->set_mask.p, smask.data(), (size_t)nsb * 8, hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(c, h2d_keep(c, c->set_base.p, sbase, (size_t)nsb));
+                HIP_TRY(c, h2d_keep(c, c->set_mask.p, smask, (size_t)nsb));
                 {
                     Prof p(c, SAGE_K_MISC);
                     HIP_TRY(c, hipMemsetAsync(c->set.p, 0xFF, slots * 8, c->stream));
@@ -705,6 +720,7 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
         }
         if (shrink) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
+            c->keep32.clear(); c->keep64.clear();
             collect_events(c);
             if (c->batch_bytes <= 4096) return fail(c, SAGE_E_LIMIT, "position pairs overflow 32-bit offsets even in the smallest batches");
             c->batch_bytes = std::max<int64_t>(c->batch_bytes / 2, 4096);     // every retry halves it: the loop ends
@@ -718,6 +734,7 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
         HIP_TRY(c, hipMemcpyAsync(flags, c->flags.p, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipMemcpyAsync(stats, c->stats.p, sizeof(stats), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->keep32.clear(); c->keep64.clear();
         collect_events(c);
         if (flags[FLAG_EMPTY_LINE])
             return fail(c, SAGE_E_EMPTY_LINE, "not enough values to unpack (expected 3, got 0)");
@@ -727,7 +744,15 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
             continue;
         }
         if (flags[FLAG_BUCKET_OVERFLOW]) {
-            if (c->exact_buckets) return fail(c, SAGE_E_LIMIT, "a key bucket overflowed its exact size");
+            if (c->exact_buckets) {
+                // Must not happen (the regions were sized by a counting pass over the same keys), but it was seen once: 1M
+                // lines of a lexicon the vocabulary was not built from (146 M tokens, 4.2e9 position pairs, hot buckets of
+                // repeated keys) -- and not when the stream was synchronised between the scatter and the dedupe kernel.
+                // Unexplained (open questions); the per-segment HBM sets are exact whatever the key statistics.
+                if (c->count_mode == 1 || c->count_fallback) return fail(c, SAGE_E_LIMIT, "a key bucket overflowed its exact size");
+                c->count_fallback = true;
+                continue;
+            }
             c->exact_buckets = true;   // heavily repeated keys: redo the step with the counting pass
             continue;
         }

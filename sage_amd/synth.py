@@ -89,15 +89,19 @@ def make_lexicon(rng: np.random.Generator, n_types: int, style: str = "en"):
 
 def make_corpus(n_lines: int, seed: int = DEFAULT_SEED, style: str = "en", n_types: int | None = None,
                 mean_log_words: float = 4.3, sigma_log_words: float = 0.6, chunk_lines: int = 50_000,
-                progress=None):
+                progress=None, line_seed: int = 0):
     """Returns (corpus uint8[nbytes], line_offsets int64[n_lines+1]); every line ends with b'.\\n'.
 
     Words/line ~ max(5, LogNormal(mean_log_words, sigma_log_words)) (defaults: ~580 B/line); word types
-    ~ Zipf(1.05); first word capitalised (ASCII letters only)."""
+    ~ Zipf(1.05); first word capitalised (ASCII letters only).  `seed` fixes the lexicon (the language);
+    `line_seed` != 0 draws other lines of the same language (the shards of a multi-GPU run must share one language: the
+    vocabulary is built from a sample of `seed`'s text, and text of another lexicon tokenizes into 1.7x the tokens)."""
     rng = np.random.default_rng(seed)
     if n_types is None:
         n_types = 50_000 if n_lines <= 200_000 else 1_000_000
     lflat, loff, n_extra = make_lexicon(rng, n_types, style)
+    if line_seed:
+        rng = np.random.default_rng([seed, line_seed])
     n_all = len(loff) - 1
     p = np.empty(n_all, dtype=np.float64)
     p[:n_all - n_extra] = (np.arange(1, n_all - n_extra + 1, dtype=np.float64)) ** -1.05

@@ -9,7 +9,10 @@ N = int(os.environ.get('SB_LINES', '300000'))
 seed = synth.DEFAULT_SEED
 head, ho = synth.make_corpus(14000, seed=seed, style="en", n_types=1_000_000)
 vocab = synth.make_vocab(head, ho, 262144, 16, sample_bytes=6_000_000)
-corpus, off = synth.make_corpus(N, seed=seed, style="en", n_types=1_000_000)
+if os.environ.get("SB_SEED_OFF"):      # text of ANOTHER lexicon than the vocabulary's: 1.7x the tokens, heavily repeated keys (fallback paths)
+    corpus, off = synth.make_corpus(N, seed=seed + int(os.environ["SB_SEED_OFF"]), style="en", n_types=1_000_000)
+else:
+    corpus, off = synth.make_corpus(N, seed=seed, line_seed=int(os.environ.get("SB_LINE_SEED", "0")), style="en", n_types=1_000_000)
 e = HipSage(0); e.set_vocab(vocab, None, 16); e.set_corpus(corpus, off)
 counts = np.bincount(e.tokenize(0, N)[0], minlength=len(vocab))
 emb = synth.make_embeddings(len(vocab), int(os.environ.get('SB_DIM', '50')), seed=seed, unseen=~(counts > 0))
