@@ -231,3 +231,20 @@ def test_packed_corpus_behaves_like_a_list_of_lines():
     assert isinstance(sub, PackedCorpus) and [sub[i] for i in range(len(sub))] == lines[1:3]
     assert pc[::2] == lines[::2]
     assert pc.line_bytes(1) == "çd e\n".encode()
+
+
+def test_bench_shards_share_one_lexicon():
+    """bench.py gives rank r the lines of `line_seed=r`: other lines of the SAME lexicon (the vocabulary is built from
+    a sample of rank 0's text; text of another lexicon tokenizes into 1.7x the tokens and made rank >= 1 a different
+    workload).  line_seed=0 is the single-GPU corpus unchanged."""
+    from sage_amd import synth
+    a, ao = synth.make_corpus(3000, seed=7, n_types=4000)
+    b, bo = synth.make_corpus(3000, seed=7, n_types=4000, line_seed=0)
+    c, co = synth.make_corpus(3000, seed=7, n_types=4000, line_seed=1)
+    assert np.array_equal(a, b) and np.array_equal(ao, bo)
+    assert not np.array_equal(a[:4096], c[:4096])
+    words = lambda buf: set(buf.tobytes().lower().replace(b".\n", b" ").split())
+    wa, wc = words(a), words(c)
+    assert len(wa & wc) > 0.6 * min(len(wa), len(wc))          # same word types
+    d, _ = synth.make_corpus(3000, seed=8, n_types=4000)
+    assert len(wa & words(d)) < 0.2 * len(wa)                  # another seed is another language
