@@ -80,8 +80,9 @@ int sage_tokenize(sage_ctx* ctx, int64_t line_begin, int64_t line_end, int32_t* 
 
 /*
  * Allocation-free tokenization.  NO COUNTERPART IN THE REFERENCE: a variant of sage_tokenize for callers that cannot
- * allocate device memory at the point of the call -- code under HIP graph capture, tight serving loops that tokenize
- * request batches with the resident vocabulary, harnesses that forbid hipMalloc.  The call allocates and frees no
+ * allocate device memory at the point of the call -- tight serving loops that tokenize request batches with the
+ * resident vocabulary, harnesses that forbid hipMalloc, code that runs between the captures of a HIP graph (the call
+ * itself synchronises the stream and copies two small results to the host, so it cannot be CAPTURED).  It allocates and frees no
  * device memory: its scratch (text copy with its zero pad, line remainders, the match table, per-line counters)
  * lives in a static device array of ~10.6 MiB that every GPU the library runs on holds until the process ends.
  * Inputs and outputs are the CALLER's DEVICE buffers: d_text[n_bytes] holds the lines back to back, d_line_offsets
@@ -189,9 +190,19 @@ int sage_train_embeddings(sage_ctx* ctx, int32_t dim, int32_t window, int32_t ne
  * partitions), out[6]=bytes per stored embedding element on the main scoring pass (4 or 8), out[7]=occurrences
  * recomputed from the float64 matrix, out[8]=ids of the ablated windows (the rows the window-dot kernel gathers),
  * out[9]=occurrences whose window is kept in the id pool, out[10]=embedding dimension, out[11]=padded row width in
- * elements, out[12]=position pairs of the ablated windows (dot products evaluated), out[13..15]=0 (reserved). */
+ * elements, out[12]=position pairs of the ablated windows (dot products evaluated), out[13]=steps this context redid with the
+ * per-segment HBM sets because the partitioned distinct count failed one of its own checks (bucket sizes against the
+ * counting pass, records per tile, records read against position pairs; expected 0 -- the tests hold it there),
+ * out[14]=1 if total_triples of the last step came from the HBM sets (count mode 1 or a fallback) else 0,
+ * out[15]=1 if the key buckets were sized by a counting pass (heavily repeated keys) else 0. */
 #define SAGE_STEP_STATS 16
 int sage_get_step_stats(sage_ctx* ctx, int64_t* out /*[SAGE_STEP_STATS]*/);
+
+/* Test hook (no counterpart in the reference): runs the step's own exclusive scan over n copies of `value` and returns
+ * the 64-bit grand total and the last (32-bit, wrapping) offset.  The step decides from the 64-bit total whether a batch's
+ * position pairs fit 32-bit offsets (else it halves the batch and starts over) before anything reads the offsets; the
+ * tests feed it totals past 2^32. */
+int sage_debug_scan_total(sage_ctx* ctx, uint32_t value, int64_t n, uint64_t* out_total, uint32_t* out_last_offset);
 
 #ifdef __cplusplus
 }

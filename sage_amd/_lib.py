@@ -80,6 +80,8 @@ def load():
                                           C.c_int32, C.c_uint64, C.c_int64, C.POINTER(C.c_double), pi64]
     lib.sage_get_step_stats.restype = C.c_int
     lib.sage_get_step_stats.argtypes = [vp, pi64]
+    lib.sage_debug_scan_total.restype = C.c_int
+    lib.sage_debug_scan_total.argtypes = [vp, C.c_uint32, i64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
     _lib = lib
     return lib
 
@@ -87,7 +89,7 @@ def load():
 EXPORTED = ["sage_version", "sage_create", "sage_destroy", "sage_last_error", "sage_set_vocab", "sage_set_corpus",
             "sage_set_embeddings", "sage_tokenize", "sage_tokenize_noalloc", "sage_ablation_step", "sage_ablation_step_device",
             "sage_set_profiling", "sage_reset_kernel_times", "sage_get_kernel_times", "sage_set_batch_bytes",
-            "sage_set_match_mode", "sage_set_count_mode", "sage_set_score_mode", "sage_set_deterministic", "sage_train_embeddings", "sage_get_step_stats"]
+            "sage_set_match_mode", "sage_set_count_mode", "sage_set_score_mode", "sage_set_deterministic", "sage_train_embeddings", "sage_get_step_stats", "sage_debug_scan_total"]
 
 
 class HipSage:
@@ -262,10 +264,17 @@ class HipSage:
                                                     int(vsize), _ptr(vec, C.c_double), _ptr(counts, C.c_int64)))
         return vec, counts
 
+    def debug_scan_total(self, value: int, n: int):
+        """-> (64-bit total, last 32-bit offset) of the step's scan over n copies of `value` (sage_debug_scan_total)."""
+        total, last = C.c_uint64(0), C.c_uint32(0)
+        self._check(self._lib.sage_debug_scan_total(self._h, int(value), int(n), C.byref(total), C.byref(last)))
+        return total.value, last.value
+
     def step_stats(self):
         out = np.zeros(16, dtype=np.int64)
         self._check(self._lib.sage_get_step_stats(self._h, _ptr(out, C.c_int64)))
         return {"tokens": int(out[0]), "corpus_bytes": int(out[1]), "occurrences": int(out[2]),
                 "rows": int(out[3]), "records": int(out[4]), "pairs": int(out[5]), "emb_elem_bytes": int(out[6]),
                 "f64_fix_occurrences": int(out[7]), "window_rows": int(out[8]), "long_occurrences": int(out[9]),
-                "dim": int(out[10]), "padded_dim": int(out[11]), "window_pairs": int(out[12])}
+                "dim": int(out[10]), "padded_dim": int(out[11]), "window_pairs": int(out[12]),
+                "count_redos": int(out[13]), "count_from_hbm_sets": int(out[14]), "exact_buckets": int(out[15])}

@@ -98,6 +98,9 @@ struct sage_ctx {
     bool exact_buckets = false;   // v2 count: size the key buckets with a counting pass instead of the estimate
     int count_mode = 0;  // 0 = partition + LDS dedupe (v2), 1 = per-segment HBM sets (v1)
     bool count_fallback = false;   // an LDS set overflowed: v1 until the vocabulary or the corpus changes
+    int64_t count_redos = 0;       // steps redone with the HBM sets because a check of the partitioned count failed (never expected)
+    bool debug_part = false;       // SAGE_DEBUG_PART=1: the scatter pass is compared tile by tile and bucket by bucket with a counting pass
+    DevBuf tile_dbg;
     DevBuf ex_ids, ex_starts, ex_widths;
     DevBuf loss, occ, hist, stats, flags;
     DevBuf loss_fix;              // deterministic mode: 128-bit fixed-point loss sums, two words per id
@@ -144,6 +147,9 @@ hipError_t scratch_for_device(int device, unsigned char** out) {
     *out = g_na_ptr[device];
     return hipSuccess;
 }
+
+constexpr size_t PART_LDS_BYTES = (size_t)PART_STAGE * 8 + ((size_t)PART_NBK_MAX * 3 + PART_LONGS + 24) * 4;
+constexpr size_t SET3_LDS_BYTES = (size_t)SET3_SLOTS * 8;
 
 #define HIP_TRY(c, expr)                                                                                   \
     do {                                                                                                   \
@@ -613,36 +619,37 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
                 PartPlan PP{c->pair_off.as<uint32_t>(), c->seg_first_occ.as<uint32_t>(), c->seg_tile_off.as<uint32_t>(),
                             c->seg_bucket_base.as<uint32_t>(), c->seg_nbk_mask.as<uint32_t>(),
                             c->bucket_off.as<unsigned long long>(), nsb};
-                static bool lds_set = false;
-                const size_t part_lds = (size_t)PART_STAGE * 8 + ((size_t)PART_NBK_MAX * 3 + PART_LONGS + 24) * 4;
-                const size_t set_lds = (size_t)SET3_SLOTS * 8;
-                if (!lds_set) {   // more than 64 KiB of dynamic LDS has to be asked for (once per process)
-                    HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_key_partition3<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds));
-                    HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_key_partition3<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)part_lds));
-                    HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_key_dedupe3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)set_lds));
-                    lds_set = true;
-                }
+                const size_t part_lds = PART_LDS_BYTES;     // (more than 64 KiB of dynamic LDS: asked for per device in sage_create)
+                const size_t set_lds = SET3_LDS_BYTES;
                 k_tile_table<<<std::min<uint32_t>(cdiv(max_tiles, 256), 1024u), 256, 0, c->stream>>>(PP, max_tiles, c->tile_tab.as<uint4>());
                 const uint32_t tgrid = (uint32_t)c->n_cu;      // persistent: the stage fills a CU's LDS
                 const uint32_t ggrid = 64u;
                 std::vector<uint64_t> boff((size_t)nbk_total + 1);
                 uint64_t total = 0;
-                if (c->exact_buckets) {
+                uint2* tile_dbg = nullptr;
+                if (c->debug_part) {
+                    if ((rc = ensure(c, c->tile_dbg, (size_t)max_tiles * 8))) return rc;
+                    tile_dbg = c->tile_dbg.as<uint2>();
+                }
+                std::vector<uint32_t> cnts;
+                if (c->exact_buckets || c->debug_part) {
                     // counting pass: exact bucket sizes (taken after an estimated region overflowed)
                     HIP_TRY(c, hipMemsetAsync(c->cursor.p, 0, (size_t)std::max(nbk_total, 1u) * 4, c->stream));
                     {
                         Prof p(c, SAGE_K_PARTITION);
                         k_key_partition3<0><<<tgrid, PART_THREADS, part_lds, c->stream>>>(
                             c->desc.as<uint4>(), c->pool.as<uint32_t>(), c->occ_tok.as<uint32_t>(), A.tok_w0, PP,
-                            c->tile_tab.as<uint4>(), max_tiles, c->cursor.as<uint32_t>(), nullptr, c->flags.as<uint32_t>());
+                            c->tile_tab.as<uint4>(), max_tiles, c->cursor.as<uint32_t>(), nullptr, c->flags.as<uint32_t>(), tile_dbg);
                         k_key_giant<0><<<ggrid, 256, 0, c->stream>>>(c->desc.as<uint4>(), c->pool.as<uint32_t>(),
                                                                      c->occ_tok.as<uint32_t>(), A.tok_w0,
                                                                      c->giant_list.as<uint32_t>(), c->giant_count.as<uint32_t>(), S, PP,
                                                                      c->cursor.as<uint32_t>(), nullptr, c->flags.as<uint32_t>());
                     }
-                    std::vector<uint32_t> cnts(nbk_total);
+                    cnts.resize(nbk_total);
                     HIP_TRY(c, hipMemcpyAsync(cnts.data(), c->cursor.p, (size_t)nbk_total * 4, hipMemcpyDeviceToHost, c->stream));
                     HIP_TRY(c, hipStreamSynchronize(c->stream));
+                }
+                if (c->exact_buckets) {
                     for (uint32_t b2 = 0; b2 < nbk_total; ++b2) { boff[b2] = total; total += cnts[b2]; }
                 } else {
                     // no counting pass: the hash spreads a segment's pairs evenly over its buckets, so each region is the
@@ -664,7 +671,7 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
                     k_key_partition3<1><<<tgrid, PART_THREADS, part_lds, c->stream>>>(
                         c->desc.as<uint4>(), c->pool.as<uint32_t>(), c->occ_tok.as<uint32_t>(), A.tok_w0, PP,
                         c->tile_tab.as<uint4>(), max_tiles, c->cursor.as<uint32_t>(), c->rec_a.as<unsigned long long>(),
-                        c->flags.as<uint32_t>());
+                        c->flags.as<uint32_t>(), tile_dbg);
                 }
                 {
                     Prof p(c, SAGE_K_MISC);
@@ -673,6 +680,25 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
                                                                  c->giant_list.as<uint32_t>(), c->giant_count.as<uint32_t>(), S, PP,
                                                                  c->cursor.as<uint32_t>(), c->rec_a.as<unsigned long long>(),
                                                                  c->flags.as<uint32_t>());
+                }
+                if (c->debug_part) {      // every bucket's scatter cursor against the counting pass
+                    std::vector<uint32_t> after(nbk_total);
+                    HIP_TRY(c, hipMemcpyAsync(after.data(), c->cursor.p, (size_t)nbk_total * 4, hipMemcpyDeviceToHost, c->stream));
+                    HIP_TRY(c, hipStreamSynchronize(c->stream));
+                    uint64_t sum_cnt = 0, sum_after = 0, sum_pairs = 0;
+                    uint32_t shown = 0, differ = 0;
+                    for (uint32_t s2 = 0; s2 < nsb; ++s2) sum_pairs += spairs[s2];
+                    for (uint32_t b2 = 0; b2 < nbk_total; ++b2) {
+                        sum_cnt += cnts[b2]; sum_after += after[b2];
+                        if (cnts[b2] != after[b2]) {
+                            ++differ;
+                            if (shown++ < 16) std::fprintf(stderr, "[sage debug] bucket %u: counted %u, scattered %u, capacity %llu\n", b2, cnts[b2],
+                                                           after[b2], (unsigned long long)(boff[b2 + 1] - boff[b2]));
+                        }
+                    }
+                    std::fprintf(stderr, "[sage debug] batch of %u segments, %u tiles max, %u buckets: pairs %llu (scan total %llu + giants), counted %llu, scattered %llu, %u buckets differ, exact=%d\n",
+                                 nsb, max_tiles, nbk_total, (unsigned long long)sum_pairs, (unsigned long long)gt2[0], (unsigned long long)sum_cnt,
+                                 (unsigned long long)sum_after, differ, (int)c->exact_buckets);
                 }
                 {
                     Prof p(c, SAGE_K_COUNT);
@@ -743,17 +769,25 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
             c->pool_factor = std::max(1, c->pool_factor) * 4;   // long ablation chains: redo the step with a larger id pool
             continue;
         }
-        if (flags[FLAG_BUCKET_OVERFLOW]) {
-            if (c->exact_buckets) {
-                // Must not happen (the regions were sized by a counting pass over the same keys), but it was seen once: 1M
-                // lines of a lexicon the vocabulary was not built from (146 M tokens, 4.2e9 position pairs, hot buckets of
-                // repeated keys) -- and not when the stream was synchronised between the scatter and the dedupe kernel.
-                // Unexplained (open questions); the per-segment HBM sets are exact whatever the key statistics.
-                if (c->count_mode == 1 || c->count_fallback) return fail(c, SAGE_E_LIMIT, "a key bucket overflowed its exact size");
-                c->count_fallback = true;
-                continue;
-            }
+        if (c->debug_part)
+            std::fprintf(stderr, "[sage debug] attempt %d: flags set_overflow=%u pool_full=%u bucket_overflow=%u part_mismatch=%u; pairs %llu, records read %llu; exact_buckets=%d fallback=%d batch_bytes=%lld\n",
+                         attempt, flags[FLAG_SET_OVERFLOW], flags[FLAG_POOL_FULL], flags[FLAG_BUCKET_OVERFLOW], flags[FLAG_PART_MISMATCH],
+                         (unsigned long long)stats[STAT_PAIRS], (unsigned long long)stats[STAT_RECORDS], (int)c->exact_buckets,
+                         (int)c->count_fallback, (long long)c->batch_bytes);
+        const bool partitioned = c->count_mode == 0 && !c->count_fallback;
+        if (flags[FLAG_BUCKET_OVERFLOW] && partitioned && !c->exact_buckets) {
             c->exact_buckets = true;   // heavily repeated keys: redo the step with the counting pass
+            continue;
+        }
+        // The partitioned count checks itself: regions sized by the counting pass cannot overflow, no tile may hold more
+        // records than its stage, and the dedupe kernel must have read exactly one record per position pair.  A step
+        // that fails any of these is redone with the per-segment HBM sets (exact whatever the key statistics) and
+        // counted in step statistic 13, which the tests hold at zero.
+        if (partitioned && !flags[FLAG_SET_OVERFLOW] &&
+            (flags[FLAG_BUCKET_OVERFLOW] || flags[FLAG_PART_MISMATCH] || stats[STAT_RECORDS] != stats[STAT_PAIRS])) {
+            if (c->debug_part) return fail(c, SAGE_E_LIMIT, "the partitioned distinct count failed its own checks (SAGE_DEBUG_PART is set: no fallback)");
+            ++c->count_redos;
+            c->count_fallback = true;
             continue;
         }
         if (flags[FLAG_SET_OVERFLOW]) {
@@ -778,6 +812,9 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
         c->step_stats[10] = (int64_t)c->dim;
         c->step_stats[11] = (int64_t)c->dp;
         c->step_stats[12] = (int64_t)stats[STAT_ABPAIRS];
+        c->step_stats[13] = c->count_redos;
+        c->step_stats[14] = (c->count_mode == 1 || c->count_fallback) ? 1 : 0;   // which back end produced total_triples
+        c->step_stats[15] = c->exact_buckets ? 1 : 0;
         // The share of ROWS that float32 cannot hold says little about the share of OCCURRENCES that touch one; the
         // step just measured the latter.  Above 30 % the float64 pass costs more than the float32 copy saves: later
         // steps (until the next sage_set_embeddings) use the float64 matrix alone.  Results do not depend on this.
@@ -808,6 +845,13 @@ int sage_create(int device, sage_ctx** out_ctx) {
     if (const char* e = std::getenv("SAGE_POOL_FACTOR")) { const int v = std::atoi(e); if (v >= 0 && v <= 64) c->pool_factor = v; }
     if (scratch_for_device(device, &c->na_scratch) != hipSuccess) { delete c; return SAGE_E_HIP; }   // device is current
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return SAGE_E_HIP; }
+    // kernels that use more than 64 KiB of dynamic LDS must say so, on every device they run on (the device is current)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_key_partition3<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PART_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_key_partition3<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PART_LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_key_dedupe3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SET3_LDS_BYTES) != hipSuccess) {
+        (void)hipStreamDestroy(c->stream); delete c; return SAGE_E_HIP;
+    }
+    if (const char* e = std::getenv("SAGE_DEBUG_PART")) c->debug_part = std::atoi(e) != 0;
     if (const char* e = std::getenv("SAGE_TEST_PAIR_LIMIT")) { const long long x = std::atoll(e); if (x > 0) c->pair_limit = (uint64_t)x; }
     if (hipMalloc(&c->flags.p, FLAG_COUNT * 4) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return SAGE_E_HIP; }
     c->flags.cap = FLAG_COUNT * 4;
@@ -827,7 +871,7 @@ void sage_destroy(sage_ctx* c) {
                      &c->seg_tok_off, &c->set_base, &c->set_mask, &c->seg_pairs, &c->desc, &c->gcache, &c->bucket_off, &c->rec_a, &c->nocc, &c->occoff, &c->occ_tok,
                      &c->occ_a, &c->exact_list, &c->exact_count, &c->np_ab, &c->dot_off, &c->dots, &c->pool, &c->pool_cursor, &c->np_all, &c->pair_off, &c->seg_first_occ, &c->seg_tile_off,
                      &c->seg_bucket_base, &c->seg_nbk_mask, &c->cursor, &c->giant_list, &c->giant_count, &c->tile_tab, &c->emb32, &c->inexact, &c->inex_list, &c->inex_count, &c->long_list, &c->long_count, &c->w2v_counts, &c->w2v_keep, &c->w2v_dropped, &c->w2v_aprob, &c->w2v_aidx, &c->w2v_syn0, &c->w2v_syn1, &c->ex_ids, &c->ex_starts, &c->ex_widths, &c->loss,
-                     &c->occ, &c->hist, &c->stats, &c->flags, &c->loss_fix};
+                     &c->occ, &c->hist, &c->stats, &c->flags, &c->loss_fix, &c->tile_dbg};
     for (DevBuf* b : all) release(*b);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1269,12 +1313,17 @@ int sage_tokenize_noalloc(sage_ctx* c, const uint8_t* d_text, int64_t n_bytes, c
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (d_counts) k_widen_counts<<<cdiv(nl, 256), 256, 0, c->stream>>>(B.ntok, nl, d_counts);
     if (want_tokens && total) {
-        if ((int64_t)total > capacity) return fail(c, SAGE_E_ARG, "token capacity too small");
+        if ((int64_t)total > capacity) {
+            (void)hipStreamSynchronize(c->stream);     // k_widen_counts may still be writing the caller's d_counts
+            collect_events(c);
+            return fail(c, SAGE_E_ARG, "token capacity too small");
+        }
         k_walk_write<true><<<cdiv(nl, 256), 256, 0, c->stream>>>(d_line_offsets, 0, nl, 0, B.M, B.tokoff, nullptr, nullptr,
                                                                 nullptr, nullptr, d_ids, d_starts, d_widths);
     }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    collect_events(c);      // with profiling on, the events of this call go back to the pool (no event is created in the steady state)
     if (out_total) *out_total = (int64_t)total;
     return SAGE_OK;
 }
@@ -1356,6 +1405,24 @@ int sage_set_count_mode(sage_ctx* c, int mode) {
 int sage_set_deterministic(sage_ctx* c, int enabled) {
     if (!c) return SAGE_E_ARG;
     c->deterministic = enabled != 0;
+    return SAGE_OK;
+}
+
+int sage_debug_scan_total(sage_ctx* c, uint32_t value, int64_t n, uint64_t* out_total, uint32_t* out_last) {
+    if (!c || !out_total || !out_last || n <= 0 || n > (int64_t)1 << 30) return fail(c, SAGE_E_ARG, "bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc;
+    // the step's own scan (scan_u32) over n copies of `value`, in the buffers the step scans its pair counts in
+    if ((rc = ensure(c, c->np_all, (size_t)n * 4))) return rc;
+    if ((rc = ensure(c, c->pair_off, ((size_t)n + 1) * 4))) return rc;
+    if ((rc = ensure(c, c->grand_total, 16))) return rc;
+    HIP_TRY(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(c->np_all.p), (int)value, (size_t)n, c->stream));
+    if ((rc = scan_u32(c, c->np_all.as<uint32_t>(), (uint32_t)n, c->pair_off.as<uint32_t>(), c->grand_total.as<uint64_t>()))) return rc;
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(out_total, c->grand_total.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(out_last, c->pair_off.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    collect_events(c);
     return SAGE_OK;
 }
 

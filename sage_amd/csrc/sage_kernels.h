@@ -28,7 +28,8 @@ struct VocabDev {
 enum { FLAG_SET_OVERFLOW = 0, FLAG_ROW_OOB = 1, FLAG_EMPTY_LINE = 2, FLAG_COUNT = 8 };
 enum { STAT_OCC = 0, STAT_ROWS = 1, STAT_PAIRS = 2, STAT_DISTINCT = 3, STAT_INEXACT = 4, STAT_WROWS = 5 /* ids of the ablated windows: the rows k_dots gathers */,
        STAT_LONG = 6 /* occurrences whose window went to the id pool */, STAT_ABPAIRS = 7 /* position pairs of the ablated windows */,
-       STAT_COUNT = 8 };
+       STAT_RECORDS = 8 /* key records the dedupe kernel read: must equal STAT_PAIRS, every record scattered and read once */,
+       STAT_COUNT = 12 };
 
 // ----------------------------------------------------------------------------------------------------------
 // rem[p] = min(255, line_end(p) - p): one byte per corpus byte, computed once per corpus (set_corpus).
@@ -774,6 +775,16 @@ __global__ __launch_bounds__(256) void k_scan_tile_sums(const uint32_t* __restri
 __global__ __launch_bounds__(256) void k_scan_top(uint32_t* __restrict__ tile_sums, uint32_t n_tiles,
                                                   uint64_t* __restrict__ grand_total) {
     __shared__ uint32_t lds[8];
+    __shared__ unsigned long long wide[4];
+    // The grand total is summed in 64 bits on its own: the host decides from it whether the 32-bit offsets below can be
+    // trusted at all (a batch with 2^32 or more items wraps them, and must be cut smaller before anything reads them).
+    unsigned long long mine = 0;
+    for (uint32_t i = threadIdx.x; i < n_tiles; i += 256) mine += tile_sums[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_down(mine, d, 64);
+    if ((threadIdx.x & 63u) == 0) wide[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) *grand_total = wide[0] + wide[1] + wide[2] + wide[3];
     uint32_t carry = 0;
     for (uint32_t b = 0; b < n_tiles; b += 256) {
         const uint32_t i = b + threadIdx.x;
@@ -782,7 +793,6 @@ __global__ __launch_bounds__(256) void k_scan_top(uint32_t* __restrict__ tile_su
         if (i < n_tiles) tile_sums[i] = carry + ex;
         carry += tot;
     }
-    if (threadIdx.x == 0) *grand_total = carry;
 }
 
 __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__ in, uint32_t n,

@@ -13,7 +13,8 @@
 #define DESC_ACC (1 << DESC_ACC_BITS)
 #define DESC_SPAN 2048      // corpus positions of the match table one k_describe tile stages in LDS
 enum { FLAG_POOL_FULL = 3, FLAG_BUCKET_OVERFLOW = 4,
-       FLAG_NAN_PAIR = 5 };   // not an error: a base token's float32 row is NaN-marked, the float64 pair pass has work
+       FLAG_NAN_PAIR = 5,     // not an error: a base token's float32 row is NaN-marked, the float64 pair pass has work
+       FLAG_PART_MISMATCH = 6 };   // the distinct count's passes disagree with the per-occurrence pair counts (never seen; checked)
 
 // ----------------------------------------------------------------------------------------------------------
 // Per-block accumulation cache in LDS for the vocabulary-sized result vectors.  Token frequencies are Zipfian: a few

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void k_count_sets(const uint4* __restrict__ de
 #define PART_GIANT SAGE_PART_GIANT
 #define PART_FILL (PART_STAGE - PART_GIANT)
 #define PART_NBK_MAX 2048u
-#define PART_LONGS 512u          // long occurrences one tile can hold (each has > 15 pairs)
+#define PART_LONGS 512u          // pooled occurrences a tile lists (a tile with more scans its headers instead)
 #define PART_INVALID 0xFFFFFFFFu
 #define SET3_SLOTS 16384u        // 128 KiB LDS set
 #define SET3_FILL 10240u         // records offered to one set pass (load <= 0.625)
@@ -258,7 +258,8 @@ __global__ __launch_bounds__(PART_THREADS) void k_key_partition3(const uint4* __
                                                                  const uint32_t* __restrict__ tok_w0, PartPlan P,
                                                                  const uint4* __restrict__ tile_tab, uint32_t max_tiles,
                                                                  uint32_t* __restrict__ cursor /* [n_buckets] records placed so far */,
-                                                                 unsigned long long* __restrict__ rec, uint32_t* __restrict__ flags) {
+                                                                 unsigned long long* __restrict__ rec, uint32_t* __restrict__ flags,
+                                                                 uint2* __restrict__ tile_dbg /* debug: (records, pooled) per tile, or nullptr */) {
     extern __shared__ unsigned long long part_lds[];
     unsigned long long* stage = part_lds;                                     // [PART_STAGE]
     uint32_t* cnt = reinterpret_cast<uint32_t*>(stage + PART_STAGE);          // [PART_NBK_MAX]
@@ -286,8 +287,12 @@ __global__ __launch_bounds__(PART_THREADS) void k_key_partition3(const uint4* __
             load_inline(desc, occ_tok, tok_w0, o, X);
             if (X.d[0] & SAGE_DH_GIANT) continue;                             // k_key_giant's
             if (X.d[0] & SAGE_DH_OVER) {
+                // listed for the wave-per-occurrence loops.  A pooled occurrence has >= 27 position pairs, so a tile can hold
+                // up to (PART_STAGE - 1) / 27 = 606 of them: more than the list.  Entries past its end are NOT dropped
+                // (which ones would depend on the order the atomics land in, i.e. differ between the counting and the
+                // scatter pass): a tile whose list ran full finds its pooled occurrences by scanning the headers instead.
                 const uint32_t at = atomicAdd(&misc[3], 1u);
-                if (at < PART_LONGS) longs[at] = o; else flags[FLAG_SET_OVERFLOW] = 1;   // cannot happen: > 15 pairs each
+                if (at < PART_LONGS) longs[at] = o;
                 continue;
             }
             have = true;
@@ -298,14 +303,26 @@ __global__ __launch_bounds__(PART_THREADS) void k_key_partition3(const uint4* __
         }
         __syncthreads();
         // pooled occurrences (~1.5 % of them): a wave each, so that their dependent loads (header -> pool ids) overlap
-        const uint32_t n_long = min(misc[3], PART_LONGS);
-        for (uint32_t q = tid >> 6; q < n_long; q += PART_THREADS / 64u) {
-            const uint32_t o = longs[q], t = occ_tok[o];
+        const uint32_t n_long = misc[3];
+        // every pooled occurrence of the tile, a wave each: from the list, or -- when the list ran full -- from a scan of
+        // the tile's headers (same occurrences either way, and the same in both passes)
+        auto for_pooled = [&](auto&& body) {
+            if (n_long <= PART_LONGS) {
+                for (uint32_t q = tid >> 6; q < n_long; q += PART_THREADS / 64u) body(longs[q]);
+            } else {
+                for (uint32_t o = o_lo + (tid >> 6); o < o_hi; o += PART_THREADS / 64u) {
+                    const uint32_t h = desc[(size_t)o * 4].x;
+                    if ((h & SAGE_DH_OVER) && !(h & SAGE_DH_GIANT)) body(o);
+                }
+            }
+        };
+        for_pooled([&](uint32_t o) {
+            const uint32_t t = occ_tok[o];
             const uint32_t a = SAGE_T_ID(tok_w0[t]);
             keys_of_pooled(desc, pool, tok_w0, o, t, tid & 63u, 64u, [&](uint32_t lo, uint32_t hi) {
                 atomicAdd(&cnt[sage_key_hash_a(make_key(a, lo, hi)) & mask], 1u);
             });
-        }
+        });
         __syncthreads();
         // ---- exclusive scan of the bucket counts (2 per thread), bucket ranges reserved with coalesced atomics
         {
@@ -326,7 +343,20 @@ __global__ __launch_bounds__(PART_THREADS) void k_key_partition3(const uint4* __
             const uint32_t ex = wbase + incl - v;
             cstart[2 * tid] = ex;
             cstart[2 * tid + 1] = ex + c0;
-            if (tid == PART_THREADS - 1u) misc[4] = ex + v;      // records of the tile
+            if (tid == PART_THREADS - 1u) {
+                misc[4] = ex + v;      // records of the tile
+                // a tile can hold at most PART_STAGE records by construction (k_tile_table); one that claims more means
+                // the per-occurrence pair counts and the key generators disagree: the step must not trust this count
+                if (ex + v > PART_STAGE) flags[FLAG_PART_MISMATCH] = 1;
+                if (tile_dbg) {        // debug: the counting pass records, the scatter pass compares
+                    if (MODE == 0) tile_dbg[tile] = make_uint2(ex + v, n_long);
+                    else if (tile_dbg[tile].x != ex + v || tile_dbg[tile].y != n_long) {
+                        flags[FLAG_PART_MISMATCH] = 1;
+                        printf("k_key_partition3: tile %u (segment %u, occurrences %u..%u) counted %u records / %u pooled, scatters %u / %u\n",
+                               tile, s, o_lo, o_hi, tile_dbg[tile].x, tile_dbg[tile].y, ex + v, n_long);
+                    }
+                }
+            }
         }
         __syncthreads();
         for (uint32_t b = tid; b <= mask; b += PART_THREADS) {
@@ -361,8 +391,8 @@ __global__ __launch_bounds__(PART_THREADS) void k_key_partition3(const uint4* __
                 place(X);
             }
         }
-        for (uint32_t q = tid >> 6; q < n_long; q += PART_THREADS / 64u) {
-            const uint32_t o = longs[q], t = occ_tok[o];
+        for_pooled([&](uint32_t o) {
+            const uint32_t t = occ_tok[o];
             const uint32_t a = SAGE_T_ID(tok_w0[t]);
             keys_of_pooled(desc, pool, tok_w0, o, t, tid & 63u, 64u, [&](uint32_t lo, uint32_t hi) {
                 const uint64_t key = make_key(a, lo, hi);
@@ -370,7 +400,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_key_partition3(const uint4* __
                 const uint32_t at = cstart[b] + atomicAdd(&cnt[b], 1u);
                 if (at < PART_STAGE) stage[at] = key;
             });
-        }
+        });
         __syncthreads();
         // ---- copy-out: consecutive lanes write one bucket's run.  dst = rec + delta[b] + e with delta[b] = the bucket's
         // reserved start minus its start in the stage, kept as 64-bit words over the space of cnt and gbase
@@ -450,7 +480,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_key_dedupe3(const unsigned lon
                                                               const unsigned long long* __restrict__ rec,
                                                               unsigned long long* __restrict__ stats, uint32_t* __restrict__ flags) {
     extern __shared__ unsigned long long set3[];
-    unsigned long long n_distinct = 0;
+    unsigned long long n_distinct = 0, n_read = 0;
     const uint32_t tid = threadIdx.x;
     // software pipeline over the workgroup's buckets: the records of bucket i+1 and the size and place of bucket i+2
     // are loaded while bucket i is inserted, so no global latency is exposed between buckets
@@ -483,6 +513,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_key_dedupe3(const unsigned lon
         const unsigned long long* in = rec + off0;
         cnt0 = cnt1; off0 = off1; cnt1 = cnt2; off1 = off2;
         if (cnt == 0) continue;
+        if (tid == 0) n_read += cnt;
         const uint32_t passes = (cnt + SET3_FILL - 1u) / SET3_FILL;
         for (uint32_t p = 0; p < passes; ++p) {
             __syncthreads();
@@ -501,4 +532,5 @@ __global__ __launch_bounds__(PART_THREADS) void k_key_dedupe3(const unsigned lon
 #pragma unroll
     for (int dd = 32; dd >= 1; dd >>= 1) n_distinct += __shfl_down(n_distinct, dd, 64);
     if ((tid & 63u) == 0 && n_distinct) atomicAdd(&stats[STAT_DISTINCT], n_distinct);
+    if (tid == 0 && n_read) atomicAdd(&stats[STAT_RECORDS], n_read);
 }
