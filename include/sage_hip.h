@@ -56,6 +56,21 @@ int sage_set_vocab(sage_ctx* ctx, const uint8_t* key_bytes, const int64_t* key_o
                    int64_t n_keys, int32_t max_len);
 
 /*
+ * The same for a vocabulary that only LOST keys since the last sage_set_vocab / sage_set_vocab_pruned -- what
+ * SaGeVocabBuilder does after every prune (SaGeVocabBuilder.py:159-192: `set_vocabulary(list(target_vocab.keys()))`, ids
+ * re-compacted).  old_to_new[old id] = the key's new id, or -1 if it was pruned, for every id of the previous id space
+ * (n_old = its size).  The new tables are built as by sage_set_vocab; in addition, when the match table of the whole
+ * resident corpus is still valid (a step over all lines has run since the corpus and the previous vocabulary were set),
+ * it is updated in place instead of recomputed: every key matching at a text position is a prefix of the longest one
+ * there, so each match moves to its nearest surviving ancestor-or-self -- one streamed pass over the table, two small
+ * table lookups per corpus byte, no hashing and no probes.  The steps that follow then launch no matcher.  Results are
+ * identical to sage_set_vocab with the same keys (tests: tokenization and every integer of the step, prune after prune).
+ * max_len must not change.  Falls back to plain sage_set_vocab behaviour when no valid match table is resident.
+ */
+int sage_set_vocab_pruned(sage_ctx* ctx, const uint8_t* key_bytes, const int64_t* key_offsets, const int32_t* key_ids,
+                          int64_t n_keys, int32_t max_len, const int32_t* old_to_new, int64_t n_old);
+
+/*
  * Uploads the partial corpus once per run: line i is bytes[line_offsets[i] .. line_offsets[i+1]) exactly as
  * `bytes(d, 'utf-8')` of utils.py:216 (trailing "\n" included).  Replaces the List[str] pickled to every
  * worker (utils.py:156).
@@ -148,6 +163,12 @@ int sage_set_batch_bytes(sage_ctx* ctx, int64_t bytes);
    cross-checks of the tests (different tables, different probe code). */
 int sage_set_match_mode(sage_ctx* ctx, int mode);
 
+/* Forgets the resident match table: the next step (or sage_tokenize) runs the matcher over the lines it covers, as the
+ * first step after sage_set_vocab / sage_set_corpus does.  A table completed by a step over all lines otherwise serves
+ * every later call until the vocabulary or the corpus changes.  bench.py calls this before every timed step, so that its
+ * `value` is the COLD step of BASELINE.json configs[1] (matcher included); the carried-over case is reported separately. */
+int sage_invalidate_matches(sage_ctx* ctx);
+
 /* Distinct-key counting back end: 0 = hash partition + LDS dedupe (default), 1 = per-segment sets in HBM (the
  * fallback the library takes by itself if an LDS set ever overflows).  Results are identical. */
 int sage_set_count_mode(sage_ctx* ctx, int mode);
@@ -194,7 +215,8 @@ int sage_train_embeddings(sage_ctx* ctx, int32_t dim, int32_t window, int32_t ne
  * per-segment HBM sets because the partitioned distinct count failed one of its own checks (bucket sizes against the
  * counting pass, records per tile, records read against position pairs; expected 0 -- the tests hold it there),
  * out[14]=1 if total_triples of the last step came from the HBM sets (count mode 1 or a fallback) else 0,
- * out[15]=1 if the key buckets were sized by a counting pass (heavily repeated keys) else 0. */
+ * out[15]=bit 0: the key buckets were sized by a counting pass (heavily repeated keys); bit 1: the step launched no matcher
+ * (its match table was carried over a prune by sage_set_vocab_pruned). */
 #define SAGE_STEP_STATS 16
 int sage_get_step_stats(sage_ctx* ctx, int64_t* out /*[SAGE_STEP_STATS]*/);
 

@@ -47,6 +47,8 @@ def load():
     lib.sage_last_error.argtypes = [vp]
     lib.sage_set_vocab.restype = C.c_int
     lib.sage_set_vocab.argtypes = [vp, pu8, pi64, pi32, i64, i32]
+    lib.sage_set_vocab_pruned.restype = C.c_int
+    lib.sage_set_vocab_pruned.argtypes = [vp, pu8, pi64, pi32, i64, i32, pi32, i64]
     lib.sage_set_corpus.restype = C.c_int
     lib.sage_set_corpus.argtypes = [vp, pu8, pi64, i64]
     lib.sage_set_embeddings.restype = C.c_int
@@ -69,6 +71,8 @@ def load():
     lib.sage_set_batch_bytes.argtypes = [vp, i64]
     lib.sage_set_match_mode.restype = C.c_int
     lib.sage_set_match_mode.argtypes = [vp, C.c_int]
+    lib.sage_invalidate_matches.restype = C.c_int
+    lib.sage_invalidate_matches.argtypes = [vp]
     lib.sage_set_score_mode.restype = C.c_int
     lib.sage_set_score_mode.argtypes = [vp, C.c_int]
     lib.sage_set_count_mode.restype = C.c_int
@@ -86,10 +90,10 @@ def load():
     return lib
 
 
-EXPORTED = ["sage_version", "sage_create", "sage_destroy", "sage_last_error", "sage_set_vocab", "sage_set_corpus",
+EXPORTED = ["sage_version", "sage_create", "sage_destroy", "sage_last_error", "sage_set_vocab", "sage_set_vocab_pruned", "sage_set_corpus",
             "sage_set_embeddings", "sage_tokenize", "sage_tokenize_noalloc", "sage_ablation_step", "sage_ablation_step_device",
             "sage_set_profiling", "sage_reset_kernel_times", "sage_get_kernel_times", "sage_set_batch_bytes",
-            "sage_set_match_mode", "sage_set_count_mode", "sage_set_score_mode", "sage_set_deterministic", "sage_train_embeddings", "sage_get_step_stats", "sage_debug_scan_total"]
+            "sage_set_match_mode", "sage_invalidate_matches", "sage_set_count_mode", "sage_set_score_mode", "sage_set_deterministic", "sage_train_embeddings", "sage_get_step_stats", "sage_debug_scan_total"]
 
 
 class HipSage:
@@ -150,6 +154,17 @@ class HipSage:
         ids_arr = None if ids is None else np.ascontiguousarray(ids, dtype=np.int32)
         self._check(self._lib.sage_set_vocab(self._h, _ptr(buf, C.c_uint8), _ptr(off, C.c_int64),
                                              _ptr(ids_arr, C.c_int32), n, int(max_len)))
+        self.vsize = (int(ids_arr.max()) if ids_arr is not None else n - 1) + 1
+
+    def set_vocab_pruned(self, flat: np.ndarray, off: np.ndarray, ids, max_len: int, old_to_new: np.ndarray):
+        """sage_set_vocab_pruned: the new (packed) vocabulary only lost keys; old_to_new[old id] = new id or -1.  A valid
+        resident match table is carried over instead of recomputed."""
+        n = len(off) - 1
+        buf = flat if flat.size else np.zeros(1, dtype=np.uint8)
+        ids_arr = None if ids is None else np.ascontiguousarray(ids, dtype=np.int32)
+        o2n = np.ascontiguousarray(old_to_new, dtype=np.int32)
+        self._check(self._lib.sage_set_vocab_pruned(self._h, _ptr(buf, C.c_uint8), _ptr(off, C.c_int64),
+                                                    _ptr(ids_arr, C.c_int32), n, int(max_len), _ptr(o2n, C.c_int32), len(o2n)))
         self.vsize = (int(ids_arr.max()) if ids_arr is not None else n - 1) + 1
 
     def set_corpus(self, corpus: np.ndarray, line_offsets: np.ndarray):
@@ -242,6 +257,10 @@ class HipSage:
     def set_match_mode(self, mode: int):
         self._check(self._lib.sage_set_match_mode(self._h, int(mode)))
 
+    def invalidate_matches(self):
+        """The next step runs the matcher again (a cold step), whatever match table is resident."""
+        self._check(self._lib.sage_invalidate_matches(self._h))
+
     def set_count_mode(self, mode: int):
         self._check(self._lib.sage_set_count_mode(self._h, int(mode)))
 
@@ -277,4 +296,5 @@ class HipSage:
                 "rows": int(out[3]), "records": int(out[4]), "pairs": int(out[5]), "emb_elem_bytes": int(out[6]),
                 "f64_fix_occurrences": int(out[7]), "window_rows": int(out[8]), "long_occurrences": int(out[9]),
                 "dim": int(out[10]), "padded_dim": int(out[11]), "window_pairs": int(out[12]),
-                "count_redos": int(out[13]), "count_from_hbm_sets": int(out[14]), "exact_buckets": int(out[15])}
+                "count_redos": int(out[13]), "count_from_hbm_sets": int(out[14]), "exact_buckets": int(out[15]) & 1,
+                "no_matcher": (int(out[15]) >> 1) & 1}

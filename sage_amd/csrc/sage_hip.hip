@@ -61,7 +61,15 @@ struct sage_ctx {
     std::string err;
 
     // vocabulary
-    DevBuf buckets, keys, byte_id, direct2, bloom, pmask, pmask8, ebk;
+    DevBuf buckets, keys, byte_id, direct2, bloom, pmask, pmask8, ebk, parent;
+    DevBuf parent_old, old_to_new, remap;   // sage_set_vocab_pruned: the previous vocabulary's parents, its id map, the match remap
+    // The match table of the WHOLE resident corpus (8 B per byte), kept across steps when it fits m_resident_max: a
+    // vocabulary that only lost keys (what SaGe does between steps) then needs no matching at all -- every match moves
+    // to its nearest surviving prefix, a table lookup per corpus byte (sage_set_vocab_pruned).
+    bool m_whole = false;      // M covers the whole corpus (indexed by absolute position) rather than one batch
+    bool m_valid = false;      // ... and holds the matches of the current vocabulary for every position
+    int64_t m_resident_max = 96ll << 30;
+    int64_t steps_without_matcher = 0;   // steps that found M valid and launched no matcher
     DevBuf vk_bytes, vk_off, vk_ids;   // packed keys as uploaded (input of k_vocab_build)
     uint32_t enb = 0;
     int match_mode = 0;  // 0 = LDS-filtered persistent matcher with queued probes, 1 = plain matcher, 2 = LDS-filtered with column probes
@@ -252,7 +260,7 @@ struct MatchBufs {
 void launch_match_and_count(sage_ctx* c, const MatchBufs& B, int64_t line0, uint32_t nl, int64_t pos0, uint64_t nb) {
     VocabDev v{c->buckets.as<uint4>(), c->bucket_mask, c->keys.as<uint64_t>(), c->key_plane, c->byte_id.as<uint32_t>(),
                c->direct2.as<uint32_t>(), c->bloom.as<uint32_t>(), c->pmask.p, c->pmask8.p, c->max_len,
-               c->ebk.as<uint4>(), c->enb};
+               c->ebk.as<uint4>(), c->enb, c->parent.as<uint32_t>()};
     if (nb) {
         Prof p(c, SAGE_K_MATCH);
         const uint32_t grid = cdiv(nb, 256);
@@ -286,6 +294,9 @@ void launch_match_and_count(sage_ctx* c, const MatchBufs& B, int64_t line0, uint
     scan_u32_with(c, B.nocc, nl, B.occoff, B.grand_total + 1, B.tile_sums);
 }
 
+// M of the batch that starts at corpus position pos0
+inline uint2* batch_M(const sage_ctx* c, int64_t pos0) { return c->M.as<uint2>() + (c->m_whole ? pos0 : 0); }
+
 // The same over lines [line0, line1) of the resident corpus, into the context's buffers.  out_total (optional) syncs.
 int match_and_count(sage_ctx* c, int64_t line0, int64_t line1, uint64_t* out_total) {
     const int64_t pos0 = c->h_line_off[line0];
@@ -293,17 +304,17 @@ int match_and_count(sage_ctx* c, int64_t line0, int64_t line1, uint64_t* out_tot
     const uint32_t nl = (uint32_t)(line1 - line0);
     if (nb >= 0xFFFFFF00ull) return fail(c, SAGE_E_LIMIT, "a batch must stay under 4 GiB of corpus bytes");
     int rc;
-    if ((rc = ensure(c, c->M, std::max<uint64_t>(nb, 1) * sizeof(uint2)))) return rc;
+    if ((rc = ensure(c, c->M, std::max<uint64_t>(c->m_whole ? (uint64_t)c->nbytes : nb, 1) * sizeof(uint2)))) return rc;
     if ((rc = ensure(c, c->ntok, (size_t)nl * 4))) return rc;
     if ((rc = ensure(c, c->nocc, (size_t)nl * 4))) return rc;
     if ((rc = ensure(c, c->tokoff, ((size_t)nl + 1) * 4))) return rc;
     if ((rc = ensure(c, c->occoff, ((size_t)nl + 1) * 4))) return rc;
     if ((rc = ensure(c, c->grand_total, 16))) return rc;
     if ((rc = ensure(c, c->tile_sums, (size_t)scan_tiles(nl) * 4))) return rc;
-    const MatchBufs B{c->corpus.as<uint8_t>(), c->rem.as<uint8_t>(), c->line_off.as<int64_t>(), c->M.as<uint2>(),
+    const MatchBufs B{c->corpus.as<uint8_t>(), c->rem.as<uint8_t>(), c->line_off.as<int64_t>(), batch_M(c, pos0),
                       c->ntok.as<uint32_t>(), c->nocc.as<uint32_t>(), c->tokoff.as<uint32_t>(), c->occoff.as<uint32_t>(),
                       c->tile_sums.as<uint32_t>(), c->grand_total.as<uint64_t>(), c->flags.as<uint32_t>()};
-    launch_match_and_count(c, B, line0, nl, pos0, nb);
+    launch_match_and_count(c, B, line0, nl, pos0, c->m_valid ? 0 : nb);      // a valid M needs no matcher, only the walks
     HIP_TRY(c, hipGetLastError());
     if (out_total) {
         uint64_t tot = 0;
@@ -515,12 +526,12 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
             {
                 Prof p(c, SAGE_K_WALK);
                 k_walk_write<false><<<cdiv(nl, 256), 256, 0, c->stream>>>(
-                    c->line_off.as<int64_t>(), line0, nl, pos0, c->M.as<uint2>(), c->tokoff.as<uint32_t>(),
+                    c->line_off.as<int64_t>(), line0, nl, pos0, batch_M(c, pos0), c->tokoff.as<uint32_t>(),
                     c->occoff.as<uint32_t>(), c->tok_w0.as<uint32_t>(), c->occ_pos.as<uint32_t>(),
                     c->occ_tok.as<uint32_t>(), nullptr, nullptr, nullptr);
             }
             if (n_occ == 0) { HIP_TRY(c, hipGetLastError()); sa = sb; continue; }
-            WalkArrays A{c->M.as<uint2>(), (uint32_t)(c->h_line_off[line1] - pos0), c->tok_w0.as<uint32_t>(), c->occ_pos.as<uint32_t>()};
+            WalkArrays A{batch_M(c, pos0), (uint32_t)(c->h_line_off[line1] - pos0), c->tok_w0.as<uint32_t>(), c->occ_pos.as<uint32_t>()};
             if ((rc = ensure(c, c->set_base, (size_t)nsb * 8))) return rc;
             if ((rc = ensure(c, c->set_mask, (size_t)nsb * 8))) return rc;
             if ((rc = ensure(c, c->seg_pairs, (size_t)nsb * 8))) return rc;
@@ -797,6 +808,9 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
         }
         if (flags[FLAG_ROW_OOB])
             return fail(c, SAGE_E_ROW, "a token id is out of bounds for the embedding matrix");
+        const bool ran_without_matcher = c->m_valid;
+        if (c->m_valid) ++c->steps_without_matcher;
+        else if (c->m_whole && n_seg > 0 && bounds[0] == 0 && bounds[n_seg] == c->n_lines) c->m_valid = true;   // every line was matched
         totals[0] = (int64_t)total_tokens;
         totals[1] = (int64_t)stats[STAT_DISTINCT];
         c->step_stats[0] = (int64_t)total_tokens;
@@ -814,7 +828,7 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
         c->step_stats[12] = (int64_t)stats[STAT_ABPAIRS];
         c->step_stats[13] = c->count_redos;
         c->step_stats[14] = (c->count_mode == 1 || c->count_fallback) ? 1 : 0;   // which back end produced total_triples
-        c->step_stats[15] = c->exact_buckets ? 1 : 0;
+        c->step_stats[15] = (c->exact_buckets ? 1 : 0) | (ran_without_matcher ? 2 : 0);
         // The share of ROWS that float32 cannot hold says little about the share of OCCURRENCES that touch one; the
         // step just measured the latter.  Above 30 % the float64 pass costs more than the float32 copy saves: later
         // steps (until the next sage_set_embeddings) use the float64 matrix alone.  Results do not depend on this.
@@ -852,6 +866,7 @@ int sage_create(int device, sage_ctx** out_ctx) {
         (void)hipStreamDestroy(c->stream); delete c; return SAGE_E_HIP;
     }
     if (const char* e = std::getenv("SAGE_DEBUG_PART")) c->debug_part = std::atoi(e) != 0;
+    if (const char* e = std::getenv("SAGE_M_RESIDENT_MAX_GB")) { const long long x = std::atoll(e); if (x >= 0) c->m_resident_max = (int64_t)x << 30; }
     if (const char* e = std::getenv("SAGE_TEST_PAIR_LIMIT")) { const long long x = std::atoll(e); if (x > 0) c->pair_limit = (uint64_t)x; }
     if (hipMalloc(&c->flags.p, FLAG_COUNT * 4) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return SAGE_E_HIP; }
     c->flags.cap = FLAG_COUNT * 4;
@@ -866,7 +881,7 @@ void sage_destroy(sage_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     collect_events(c);
     for (auto e : c->ev_free) (void)hipEventDestroy(e);
-    DevBuf* all[] = {&c->buckets, &c->keys, &c->ebk, &c->vk_bytes, &c->vk_off, &c->vk_ids, &c->byte_id, &c->direct2, &c->bloom, &c->pmask, &c->pmask8, &c->corpus, &c->rem, &c->line_off, &c->emb, &c->M, &c->ntok,
+    DevBuf* all[] = {&c->buckets, &c->keys, &c->ebk, &c->parent, &c->parent_old, &c->old_to_new, &c->remap, &c->vk_bytes, &c->vk_off, &c->vk_ids, &c->byte_id, &c->direct2, &c->bloom, &c->pmask, &c->pmask8, &c->corpus, &c->rem, &c->line_off, &c->emb, &c->M, &c->ntok,
                      &c->tokoff, &c->tile_sums, &c->grand_total, &c->tok_w0, &c->occ_pos, &c->set, &c->seg_line_rel,
                      &c->seg_tok_off, &c->set_base, &c->set_mask, &c->seg_pairs, &c->desc, &c->gcache, &c->bucket_off, &c->rec_a, &c->nocc, &c->occoff, &c->occ_tok,
                      &c->occ_a, &c->exact_list, &c->exact_count, &c->np_ab, &c->dot_off, &c->dots, &c->pool, &c->pool_cursor, &c->np_all, &c->pair_off, &c->seg_first_occ, &c->seg_tile_off,
@@ -932,6 +947,7 @@ int sage_set_vocab(sage_ctx* c, const uint8_t* key_bytes, const int64_t* key_off
     const size_t total_key_bytes = (size_t)key_offsets[n_keys];
     int rc;
     c->have_vocab = false;      // the tables are rewritten in place: no vocabulary until all of them are complete
+    c->m_valid = false;         // (sage_set_vocab_pruned re-validates the match table after it has moved the matches)
     if ((rc = ensure(c, c->buckets, nbuckets * 16))) return rc;
     if ((rc = ensure(c, c->keys, key_plane * (size_t)nw * 8))) return rc;
     if ((rc = ensure(c, c->ebk, (size_t)enb * 64))) return rc;
@@ -940,6 +956,7 @@ int sage_set_vocab(sage_ctx* c, const uint8_t* key_bytes, const int64_t* key_off
     if ((rc = ensure(c, c->bloom, SAGE_BLOOM_BITS / 8))) return rc;
     if ((rc = ensure(c, c->pmask, (size_t)SAGE_PMASK_SLOTS * 4))) return rc;
     if ((rc = ensure(c, c->pmask8, (size_t)SAGE_PMASK8_SLOTS * 4))) return rc;
+    if ((rc = ensure(c, c->parent, ((size_t)max_id + 1) * 4))) return rc;
     if ((rc = ensure(c, c->vk_bytes, total_key_bytes + 16))) return rc;
     if ((rc = ensure(c, c->vk_off, (size_t)(n_keys + 1) * 8))) return rc;
     if (key_ids && (rc = ensure(c, c->vk_ids, (size_t)n_keys * 4))) return rc;
@@ -955,12 +972,26 @@ int sage_set_vocab(sage_ctx* c, const uint8_t* key_bytes, const int64_t* key_off
     HIP_TRY(c, hipMemsetAsync(c->bloom.p, 0, SAGE_BLOOM_BITS / 8, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->pmask.p, 0, (size_t)SAGE_PMASK_SLOTS * 4, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->pmask8.p, 0, (size_t)SAGE_PMASK8_SLOTS * 4, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->parent.p, 0, ((size_t)max_id + 1) * 4, c->stream));
     VocabBuild vb{c->vk_bytes.as<uint8_t>(), c->vk_off.as<int64_t>(), key_ids ? c->vk_ids.as<int32_t>() : nullptr, (uint32_t)n_keys,
                   (uint32_t)max_len, nw, c->buckets.as<uint32_t>(), bmask, c->keys.as<uint64_t>(), (uint32_t)key_plane,
                   c->byte_id.as<uint32_t>(), c->direct2.as<uint32_t>(), c->bloom.as<uint32_t>(), c->pmask.as<uint32_t>(),
                   c->pmask8.as<uint32_t>(), pm16 ? 1 : 0, c->ebk.as<uint32_t>(), enb};
     k_vocab_build<<<cdiv((uint64_t)n_keys, 256), 256, 0, c->stream>>>(vb);
     HIP_TRY(c, hipGetLastError());
+    {   // parent[id]: the longest proper prefix that is a key (probes the tables the kernel above has just completed)
+        const VocabDev vd{c->buckets.as<uint4>(), bmask, c->keys.as<uint64_t>(), (uint32_t)key_plane, c->byte_id.as<uint32_t>(),
+                          c->direct2.as<uint32_t>(), c->bloom.as<uint32_t>(), c->pmask.p, c->pmask8.p, max_len,
+                          c->ebk.as<uint4>(), enb, nullptr};
+        const uint32_t pgrid = cdiv((uint64_t)n_keys, 256);
+        switch (nw) {
+        case 1: k_vocab_parents<1><<<pgrid, 256, 0, c->stream>>>(vb, vd, c->parent.as<uint32_t>()); break;
+        case 2: k_vocab_parents<2><<<pgrid, 256, 0, c->stream>>>(vb, vd, c->parent.as<uint32_t>()); break;
+        case 3: k_vocab_parents<3><<<pgrid, 256, 0, c->stream>>>(vb, vd, c->parent.as<uint32_t>()); break;
+        default: k_vocab_parents<4><<<pgrid, 256, 0, c->stream>>>(vb, vd, c->parent.as<uint32_t>()); break;
+        }
+        HIP_TRY(c, hipGetLastError());
+    }
     uint32_t byte_id[256];
     HIP_TRY(c, hipMemcpyAsync(byte_id, c->byte_id.p, sizeof byte_id, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -978,6 +1009,44 @@ int sage_set_vocab(sage_ctx* c, const uint8_t* key_bytes, const int64_t* key_off
     c->have_vocab = true;
     c->exact_buckets = false;      // fallbacks a step took because of the old vocabulary's key statistics
     c->count_fallback = false;
+    return SAGE_OK;
+}
+
+int sage_set_vocab_pruned(sage_ctx* c, const uint8_t* key_bytes, const int64_t* key_offsets, const int32_t* key_ids,
+                          int64_t n_keys, int32_t max_len, const int32_t* old_to_new, int64_t n_old) {
+    if (!c || !old_to_new) return fail(c, SAGE_E_ARG, "bad argument");
+    if (!c->have_vocab) return fail(c, SAGE_E_STATE, "sage_set_vocab_pruned follows a sage_set_vocab");
+    if (max_len != c->max_len) return fail(c, SAGE_E_ARG, "sage_set_vocab_pruned must keep max_len");
+    if (n_old != c->max_id + 1) return fail(c, SAGE_E_ARG, "old_to_new must cover the previous vocabulary's id space");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const bool move_matches = c->m_valid;
+    // the previous vocabulary's parents outlive the rebuild: the remap below walks them
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::swap(c->parent, c->parent_old);
+    int rc = sage_set_vocab(c, key_bytes, key_offsets, key_ids, n_keys, max_len);     // (leaves m_valid false)
+    if (rc) return rc;
+    if (!move_matches) return SAGE_OK;
+    for (int64_t i = 0; i < n_old; ++i)
+        if (old_to_new[i] < -1 || old_to_new[i] > c->max_id) return fail(c, SAGE_E_ARG, "old_to_new holds an id outside the new vocabulary");
+    if ((rc = ensure(c, c->old_to_new, (size_t)n_old * 4))) return rc;
+    if ((rc = ensure(c, c->remap, (size_t)n_old * 4))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->old_to_new.p, old_to_new, (size_t)n_old * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->flags.p, 0, FLAG_COUNT * 4, c->stream));
+    k_build_remap<<<cdiv((uint64_t)n_old, 256), 256, 0, c->stream>>>(c->old_to_new.as<int32_t>(), c->parent_old.as<uint32_t>(),
+                                                                     (uint32_t)n_old, c->remap.as<uint32_t>());
+    {
+        Prof p(c, SAGE_K_MATCH);       // what replaces the matcher on this step
+        k_remap_matches<<<(uint32_t)std::min<uint64_t>(((uint64_t)c->nbytes + 255) / 256, (uint64_t)c->n_cu * 32u), 256, 0, c->stream>>>(
+            c->M.as<uint2>(), (uint64_t)c->nbytes, c->remap.as<uint32_t>(), (uint32_t)n_old, c->parent.as<uint32_t>(), c->flags.as<uint32_t>());
+    }
+    HIP_TRY(c, hipGetLastError());
+    uint32_t flags[FLAG_COUNT];
+    HIP_TRY(c, hipMemcpyAsync(flags, c->flags.p, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));     // (old_to_new is the caller's: the copy above has completed)
+    collect_events(c);
+    // a match whose every prefix was pruned cannot exist (single bytes are never pruned): the table stays invalid if one did
+    if (flags[FLAG_SET_OVERFLOW]) return SAGE_OK;
+    c->m_valid = true;
     return SAGE_OK;
 }
 
@@ -1004,6 +1073,8 @@ int sage_set_corpus(sage_ctx* c, const uint8_t* bytes, const int64_t* line_offse
     for (int64_t l = 0; l < n_lines; ++l) c->max_line_bytes = std::max(c->max_line_bytes, line_offsets[l + 1] - line_offsets[l]);
     c->n_lines = n_lines;
     c->nbytes = nbytes;
+    c->m_valid = false;
+    c->m_whole = nbytes > 0 && nbytes * 8 <= c->m_resident_max;
     if (nbytes) {
         k_line_remaining<<<(uint32_t)std::min<uint64_t>(((uint64_t)nbytes + 255) / 256, 1u << 20), 256, 0, c->stream>>>(
             c->line_off.as<int64_t>(), n_lines, c->rem.as<uint8_t>(), nbytes);
@@ -1074,7 +1145,7 @@ static int w2v_tokenize_batch(sage_ctx* c, int64_t l0, int64_t l1, uint32_t* n_t
     if ((rc = ensure(c, c->occ_pos, (size_t)std::max(n_occ, 1u) * 4))) return rc;
     if ((rc = ensure(c, c->occ_tok, (size_t)std::max(n_occ, 1u) * 4))) return rc;
     k_walk_write<false><<<cdiv(nl, 256), 256, 0, c->stream>>>(
-        c->line_off.as<int64_t>(), l0, nl, c->h_line_off[l0], c->M.as<uint2>(), c->tokoff.as<uint32_t>(),
+        c->line_off.as<int64_t>(), l0, nl, c->h_line_off[l0], batch_M(c, c->h_line_off[l0]), c->tokoff.as<uint32_t>(),
         c->occoff.as<uint32_t>(), c->tok_w0.as<uint32_t>(), c->occ_pos.as<uint32_t>(), c->occ_tok.as<uint32_t>(),
         nullptr, nullptr, nullptr);
     HIP_TRY(c, hipGetLastError());
@@ -1244,7 +1315,7 @@ int sage_tokenize(sage_ctx* c, int64_t line_begin, int64_t line_end, int32_t* ou
             {
                 Prof p(c, SAGE_K_WALK);
                 k_walk_write<true><<<cdiv(nl, 256), 256, 0, c->stream>>>(
-                    c->line_off.as<int64_t>(), l0, nl, c->h_line_off[l0], c->M.as<uint2>(), c->tokoff.as<uint32_t>(),
+                    c->line_off.as<int64_t>(), l0, nl, c->h_line_off[l0], batch_M(c, c->h_line_off[l0]), c->tokoff.as<uint32_t>(),
                     nullptr, nullptr, nullptr, nullptr, c->ex_ids.as<int32_t>(), c->ex_starts.as<int32_t>(),
                     c->ex_widths.as<int32_t>());
             }
@@ -1386,6 +1457,13 @@ int sage_set_batch_bytes(sage_ctx* c, int64_t bytes) {
 int sage_set_match_mode(sage_ctx* c, int mode) {
     if (!c || mode < 0 || mode > 2) return fail(c, SAGE_E_ARG, "match mode must be 0, 1 or 2");
     c->match_mode = mode;
+    c->m_valid = false;      // the next step matches again, with the matcher that was asked for
+    return SAGE_OK;
+}
+
+int sage_invalidate_matches(sage_ctx* c) {
+    if (!c) return SAGE_E_ARG;
+    c->m_valid = false;
     return SAGE_OK;
 }
 

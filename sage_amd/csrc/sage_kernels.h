@@ -23,6 +23,10 @@ struct VocabDev {
                               // {u64 first 8 key bytes [4]; u32 id | (len-1) << 20 [4]; u32 key bytes 8..11 [4]}, keys of >= 3 bytes.
                               // A probe is ONE cache-line request: keys of <= 12 bytes are verified from the bucket itself
     uint32_t enb;             // buckets of ebk (any number; bucket = mulhi(hash, enb))
+    const uint32_t* parent;   // [id] the longest PROPER prefix of key id that is itself a key, as id | len << 20 (every key of
+                              // 2+ bytes has one: its first byte).  The second-longest match at a text position is the
+                              // parent of the longest one -- every shorter match is a prefix of the longest -- so the
+                              // queued matcher stops probing at its first hit (k_vocab_parents builds the table)
 };
 
 enum { FLAG_SET_OVERFLOW = 0, FLAG_ROW_OOB = 1, FLAG_EMPTY_LINE = 2, FLAG_COUNT = 8 };
@@ -435,7 +439,7 @@ __device__ __forceinline__ void probe_queued(const VocabDev& v, uint32_t cand, c
                                              const uint64_t (&W)[NW], Top2& top, uint2* __restrict__ q, uint32_t lane) {
     constexpr int N = JHI - JLO + 1;
     constexpr int KW = (JHI + 7) / 8;          // key words a length of this class can reach
-    const uint32_t c = top.m2 == 0u ? cand : 0u;
+    const uint32_t c = top.m1 == 0u ? cand : 0u;   // a lane with a match is done: its second match is the parent of the first
     uint32_t pre[N];                            // queue index of this lane's entry for length JHI - i
     uint32_t total = 0;
 #pragma unroll
@@ -526,6 +530,85 @@ __device__ __forceinline__ void probe_queued(const VocabDev& v, uint32_t cand, c
             if (((c >> (j - 1)) & 1u) && pre[i] - w0 < MQ_CAP) top.fold(q[pre[i] - w0].x);
         }
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// K0b  parent[id] = the longest proper prefix of key id that is a key (id | len << 20); one thread per key, after
+// k_vocab_build has completed the tables it probes.  Prefixes of 3+ bytes are looked up in the embedded-key table from
+// the longest down, 2-byte prefixes in the direct table, the first byte always exists.
+template <int NW>
+__global__ __launch_bounds__(256) void k_vocab_parents(VocabBuild B, VocabDev v, uint32_t* __restrict__ parent) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= B.n_keys) return;
+    const uint32_t id = B.key_ids ? (uint32_t)B.key_ids[i] : i;
+    const uint8_t* k = B.key_bytes + B.key_off[i];
+    const uint32_t len = (uint32_t)(B.key_off[i + 1] - B.key_off[i]);
+    if (len > B.max_len) { parent[id] = 0u; return; }      // in no table, never matched
+    if (len == 1u) { parent[id] = 0u; return; }            // "no second match" (len2 == 0 iff len1 == 1)
+    uint64_t W[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) W[w] = 0ull;
+    uint32_t fh[8 * NW + 1];
+    uint32_t h = SAGE_FNV_OFFSET;
+    for (uint32_t j = 0; j < len; ++j) {
+        W[j >> 3] |= (uint64_t)k[j] << (8u * (j & 7u));
+        h = sage_fnv_step(h, k[j]);
+        fh[j + 1] = sage_mix32(h);
+    }
+    uint32_t out = 0u;
+    for (uint32_t L = len - 1u; L >= 3u && out == 0u; --L) {
+        uint64_t P[NW];        // the prefix's words (bytes past L zeroed: the probe compares whole words of long keys)
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const int nb = (int)L - 8 * w;
+            P[w] = nb <= 0 ? 0ull : nb >= 8 ? W[w] : (W[w] & ((1ull << (8 * nb)) - 1ull));
+        }
+        uint32_t hid;
+        if (probe_exact_e<NW>(v, __umulhi(fh[L], v.enb), P, L, hid)) out = hid | (L << 20);
+    }
+    if (out == 0u && len >= 3u) {
+        const uint32_t d2 = v.direct2[(uint32_t)k[0] | ((uint32_t)k[1] << 8)];
+        if (d2 != SAGE_SLOT_EMPTY) out = d2 | (2u << 20);
+    }
+    if (out == 0u) out = v.byte_id[k[0]] | (1u << 20);
+    parent[id] = out;
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// A vocabulary that only LOST keys (SaGe's prune, SaGeVocabBuilder.py:159-192) needs no new matching.  Every key that
+// matches at a text position is a prefix of the longest one there, so after the prune the longest match is the nearest
+// surviving ancestor-or-self of the old one in the parent chain, and the second longest is that key's parent in the new
+// vocabulary.  k_build_remap walks the OLD parent chain once per old id; k_remap_matches is then one streamed pass over
+// the match table: two lookups in tables of <= 1 MiB per corpus byte, no hashing, no probes.
+//   remap[old id] = new id | L << 20, L = 0: the key itself survives (length and "ends the line" bit stay),
+//                   L > 0: its nearest surviving ancestor, of L bytes;  0xFFFFFFFF: none (cannot happen for a matched key)
+// ----------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_build_remap(const int32_t* __restrict__ old_to_new, const uint32_t* __restrict__ parent_old,
+                                                     uint32_t n_old, uint32_t* __restrict__ remap) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_old) return;
+    uint32_t x = i, L = 0u;
+    int32_t to = old_to_new[x];
+    while (to < 0) {
+        const uint32_t p = parent_old[x];
+        if (p == 0u) { remap[i] = 0xFFFFFFFFu; return; }      // a single byte or an unmatched key without a survivor
+        x = SAGE_M_ID(p); L = SAGE_M_LEN(p);
+        to = old_to_new[x];
+    }
+    remap[i] = (uint32_t)to | (L << 20);
+}
+
+__global__ __launch_bounds__(256) void k_remap_matches(uint2* __restrict__ M, uint64_t n_pos, const uint32_t* __restrict__ remap,
+                                                       uint32_t n_old, const uint32_t* __restrict__ parent_new,
+                                                       uint32_t* __restrict__ flags) {
+    for (uint64_t p = (uint64_t)blockIdx.x * 256u + threadIdx.x; p < n_pos; p += (uint64_t)gridDim.x * 256u) {
+        const uint32_t m1 = M[p].x;
+        const uint32_t id = SAGE_M_ID(m1);
+        const uint32_t r = id < n_old ? remap[id] : 0xFFFFFFFFu;
+        if (r == 0xFFFFFFFFu) { flags[FLAG_SET_OVERFLOW] = 1; continue; }
+        const uint32_t nid = SAGE_M_ID(r), L = SAGE_M_LEN(r);
+        const uint32_t x = L == 0u ? (nid | (m1 & 0xFFF00000u)) : (nid | (L << 20));      // a shorter match cannot end the line
+        M[p] = make_uint2(x, parent_new[nid]);
     }
 }
 
@@ -634,11 +717,26 @@ __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ 
             const uint32_t c2 = top.m2 == 0u ? cand : 0u;
             if (__any((c2 & 0x0Cu) != 0u)) probe_chunk<NW, 3, 4, ML>(v, c2, fh, W, top);
         }
-        // 2-byte keys need no hash: a 256 KiB table indexed by the two bytes
-        if (top.m2 == 0u && lim >= 2u) d2 = v.direct2[T[0] & 0xFFFFu];
-        top.fold((lim >= 2u && d2 != SAGE_SLOT_EMPTY) ? (d2 | (2u << 20)) : 0u);
-        // the single byte always matches: it is the longest match when nothing else hit, the second when one did
-        if (top.m2 == 0u) top.fold(v.byte_id[T[0] & 0xFFu] | (1u << 20));
+        if constexpr (QUEUED) {
+            // The queued classes stop at a lane's first hit (the longest match).  A class that found two has the second
+            // longest too (nothing lies between them outside the class); otherwise it is the parent of the longest: one
+            // lookup in a 1 MiB table instead of the probes of every shorter candidate length.
+            if (top.m1 == 0u) {
+                // no key of 3+ bytes: 2-byte keys need no hash (a 256 KiB table indexed by the two bytes), and the single
+                // byte always matches -- the longest match when nothing else hit, the second when the 2-byte key did
+                if (lim >= 2u) d2 = v.direct2[T[0] & 0xFFFFu];
+                top.fold((lim >= 2u && d2 != SAGE_SLOT_EMPTY) ? (d2 | (2u << 20)) : 0u);
+                top.fold(v.byte_id[T[0] & 0xFFu] | (1u << 20));
+            } else if (top.m2 == 0u) {
+                top.m2 = v.parent[SAGE_M_ID(top.m1)];
+            }
+        } else {
+            // 2-byte keys need no hash: a 256 KiB table indexed by the two bytes
+            if (top.m2 == 0u && lim >= 2u) d2 = v.direct2[T[0] & 0xFFFFu];
+            top.fold((lim >= 2u && d2 != SAGE_SLOT_EMPTY) ? (d2 | (2u << 20)) : 0u);
+            // the single byte always matches: it is the longest match when nothing else hit, the second when one did
+            if (top.m2 == 0u) top.fold(v.byte_id[T[0] & 0xFFu] | (1u << 20));
+        }
         // (more than two matches may have been folded in -- a chunk probes all its lengths -- m1 and m2 are the two
         // longest of them in any case; with a single match m2 is 0 = "no second match", len2 == 0 iff len1 == 1)
         // streamed once: keep it out of the way of the table and key planes in L2

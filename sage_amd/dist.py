@@ -47,6 +47,21 @@ def barrier() -> None:
         dist.barrier()
 
 
+def assert_same_on_all_ranks(values, what: str) -> None:
+    """Raises RuntimeError on EVERY rank if the integer tuple `values` is not the same on all of them."""
+    dist = get_dist()
+    if dist is None:
+        return
+    import torch
+    mine = torch.tensor([int(v) for v in values], dtype=torch.int64)
+    lo, hi = mine.clone(), mine.clone()
+    _through_host(dist, lo, lambda x: dist.all_reduce(x, op=dist.ReduceOp.MIN))
+    _through_host(dist, hi, lambda x: dist.all_reduce(x, op=dist.ReduceOp.MAX))
+    if not torch.equal(lo, hi):
+        raise RuntimeError(f"{what} differs between ranks: this rank has {tuple(mine.tolist())}, "
+                           f"minimum {tuple(lo.tolist())}, maximum {tuple(hi.tolist())}")
+
+
 def _through_host(dist, t, fn):
     """Runs the collective `fn` on a tensor the group's backend can take; the result lands in `t`."""
     if t.is_cuda and not device_collectives(dist):
@@ -149,15 +164,54 @@ class StepBuffers:
             t.zero_()
 
 
+# exception classes a failed step is reported with on the ranks that did not fail themselves (index = status code)
+_STEP_ERRORS = (None, IndexError, ValueError, RuntimeError, Exception)
+
+
+def _status_code(exc: Optional[BaseException]) -> int:
+    if exc is None:
+        return 0
+    for code in (1, 2, 3):
+        if isinstance(exc, _STEP_ERRORS[code]):
+            return code
+    return 4
+
+
+def raise_if_any_rank_failed(dist, exc: Optional[BaseException], what: str) -> None:
+    """utils.py:167 (`res.get()` re-raises a worker's exception in the parent): the ranks exchange one status word each
+    BEFORE any data collective, so a rank whose step raised does not leave the others waiting in all_reduce.  The rank
+    that failed re-raises its own exception; every other rank raises the same class, naming the ranks that failed."""
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    status = torch.zeros(world, dtype=torch.int64)
+    status[rank] = _status_code(exc)
+    _through_host(dist, status, lambda x: dist.all_reduce(x, op=dist.ReduceOp.SUM))
+    if exc is not None:
+        raise exc
+    failed = [(r, int(c)) for r, c in enumerate(status.tolist()) if c]
+    if failed:
+        cls = _STEP_ERRORS[min(failed[0][1], 4)]
+        names = ", ".join(f"rank {r} ({_STEP_ERRORS[min(c, 4)].__name__})" for r, c in failed)
+        raise cls(f"{what} failed on {names}; this rank ({rank}) stops with it -- see that rank's log for the message")
+
+
 def step_into(engine, local_bounds, buf: StepBuffers, dist=None) -> None:
     """One ablation step of this rank's segments into `buf`, then (with a process group) the combine.
-    This is the whole per-step N>1 path; bench.py times exactly this call."""
-    if len(local_bounds) > 1:
-        engine.ablation_step_device(local_bounds, (buf.loss.data_ptr(), buf.vsize), buf.occ.data_ptr(),
-                                    buf.tot.data_ptr(), (buf.hist.data_ptr(), buf.hist_len))
-    else:
-        buf.zero_()     # a rank without segments (more ranks than count segments) contributes zeros
+    This is the whole per-step N>1 path; bench.py times exactly this call.  A step that raises on one rank raises on
+    every rank (`raise_if_any_rank_failed`)."""
+    err = None
+    try:
+        if len(local_bounds) > 1:
+            engine.ablation_step_device(local_bounds, (buf.loss.data_ptr(), buf.vsize), buf.occ.data_ptr(),
+                                        buf.tot.data_ptr(), (buf.hist.data_ptr(), buf.hist_len))
+        else:
+            buf.zero_()     # a rank without segments (more ranks than count segments) contributes zeros
+    except Exception as exc:      # noqa: BLE001 -- reported to the other ranks, then re-raised here
+        if dist is None:
+            raise
+        err = exc
     if dist is not None:
+        raise_if_any_rank_failed(dist, err, "the ablation step")
         combine(dist, buf.loss, buf.occ, buf.hist, buf.tot)
 
 
@@ -170,7 +224,13 @@ def run_sharded_step(dist, bounds: Sequence[int], line_offsets: Sequence[int],
     rank, world = dist.get_rank(), dist.get_world_size()
     lo, hi = partition_segments(bounds, line_offsets, world)[rank]
     local = np.asarray(bounds[lo:hi + 1], dtype=np.int64)
-    loss, occ, tt, ttr, hist = step_fn(local)
+    err, out = None, None
+    try:
+        out = step_fn(local)
+    except Exception as exc:      # noqa: BLE001
+        err = exc
+    raise_if_any_rank_failed(dist, err, "the ablation step")
+    loss, occ, tt, ttr, hist = out
     t_loss, t_occ, t_hist = (torch.from_numpy(np.array(a)) for a in (loss, occ, hist))
     t_tot = torch.tensor([tt, ttr], dtype=torch.int64)
     combine(dist, t_loss, t_occ, t_hist, t_tot)
@@ -186,11 +246,19 @@ def run_sage_distributed(embeddings: np.ndarray, partial_corpus, sage_model, wor
     dist = get_dist()
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist else (0, 1)
     engine = parallel.get_engine()
-    parallel.sync_vocab(engine, sage_model)
-    parallel.sync_embeddings(engine, embeddings)
-    n_lines = len(partial_corpus)
-    bounds = parallel.segment_line_bounds(n_lines, workers_number)
-    local = parallel.sync_corpus_shard(engine, partial_corpus, bounds, rank, world)
+    err, local = None, None
+    try:
+        parallel.sync_vocab(engine, sage_model)
+        parallel.sync_embeddings(engine, embeddings)
+        n_lines = len(partial_corpus)
+        bounds = parallel.segment_line_bounds(n_lines, workers_number)
+        local = parallel.sync_corpus_shard(engine, partial_corpus, bounds, rank, world)
+    except Exception as exc:      # noqa: BLE001
+        if dist is None:
+            raise
+        err = exc
+    if dist is not None:
+        raise_if_any_rank_failed(dist, err, "uploading the vocabulary, embeddings or corpus shard")
     vsize = sage_model.id_space()
     while True:
         buf = engine.cache.get("buffers")

@@ -106,19 +106,22 @@ def _read_bytes(path: Path) -> np.ndarray:
 
 
 def load_corpus_packed(corpus_filepath, partial_corpus_filepath: Optional[Path], partial_corpus_line_number: int,
-                       write: bool = True):
+                       write: bool = True, reuse: Optional[bool] = None):
     """`load_corpus` (utils.py:71-103) straight into the device layout: a `PackedCorpus` (uint8 bytes + int64 line
     offsets) from a memory map, never a Python string per line.  Same lines in the same order as the reference under
     the same `random` state -- `random.shuffle` consumes the generator as a function of the list LENGTH only, so
     shuffling the line indices gives the reference's permutation -- and the same partial-corpus file.  Bytes are
     taken as they are: the reference would raise UnicodeDecodeError on a file that is not valid UTF-8, this does not.
-    `write=False` (ranks other than 0 of a multi-GPU run) skips writing the partial-corpus file."""
+    `write=False` (ranks other than 0 of a multi-GPU run) skips writing the partial-corpus file; `reuse` overrides the
+    "does the partial-corpus file exist" test (the ranks of a multi-GPU run decide it together, before rank 0 writes)."""
     from .parallel import PackedCorpus
     corpus_filepath = Path(corpus_filepath)
     if isinstance(partial_corpus_filepath, str):
         partial_corpus_filepath = Path(partial_corpus_filepath)
     started = time.time()
-    if partial_corpus_filepath and partial_corpus_filepath.exists():
+    if reuse is None:
+        reuse = bool(partial_corpus_filepath and partial_corpus_filepath.exists())
+    if reuse:
         data = _read_bytes(partial_corpus_filepath)
         off = _split_lines(data)
         logging.info(f"partial corpus {partial_corpus_filepath.as_posix()}: {len(off) - 1} lines, {len(data)} bytes "
@@ -151,16 +154,20 @@ def load_corpus_packed(corpus_filepath, partial_corpus_filepath: Optional[Path],
 
 
 def load_corpus_for_rank(corpus_filepath, partial_corpus_filepath, partial_corpus_line_number: int, rank: int):
-    """Every rank of a multi-GPU run gets the same partial corpus: every rank starts from the same `random` state
-    (set_random_seed), so the shuffle gives the same lines everywhere; rank 0 writes the file, and the others wait
-    until it is complete before anyone can find it on disk half-written."""
+    """Every rank of a multi-GPU run gets the same partial corpus.  Whether the partial-corpus file is reused is decided
+    once, by what is on disk BEFORE anyone writes: if it exists every rank reads it; if not, every rank shuffles the
+    full corpus from the same `random` state (set_random_seed) and rank 0 alone writes the file.  (A rank that found the
+    file rank 0 had just written would re-split it -- and a line that lost its newline in the shuffle merges with its
+    successor there, utils.py:75-80 vs :84-96 -- so the ranks would disagree on the line count.)  The ranks then compare
+    line and byte counts and fail together if they differ."""
     from . import dist as sdist
-    if rank == 0:
-        corpus = load_corpus_packed(corpus_filepath, partial_corpus_filepath, partial_corpus_line_number, write=True)
-        sdist.barrier()
-        return corpus
-    sdist.barrier()
-    return load_corpus_packed(corpus_filepath, partial_corpus_filepath, partial_corpus_line_number, write=False)
+    path = Path(partial_corpus_filepath) if isinstance(partial_corpus_filepath, str) else partial_corpus_filepath
+    reuse = bool(path and path.exists())
+    sdist.barrier()                    # nobody writes before everyone has looked
+    corpus = load_corpus_packed(corpus_filepath, path, partial_corpus_line_number, write=rank == 0, reuse=reuse)
+    sdist.barrier()                    # the file is complete before anyone goes on
+    sdist.assert_same_on_all_ranks((len(corpus), int(corpus.offsets[-1]), int(reuse)), "partial corpus (lines, bytes, reused)")
+    return corpus
 
 
 def init_logger(experiment_name: str, rank: int = 0) -> None:

@@ -135,7 +135,13 @@ def sync_vocab(engine: HipSage, sage_model) -> None:
     hit = engine.cache.get("vocab")
     if hit is None or hit[0] is not sage_model or hit[1] != tag:
         flat, off, ids = sage_model.packed_key_table()
-        engine.set_vocab_packed(flat, off, ids, sage_model.max_len)
+        pm = getattr(sage_model, "prune_map", None)
+        if (hit is not None and hit[0] is sage_model and pm is not None and hit[1] == (pm[0], sage_model.max_len)
+                and os.environ.get("SAGE_INCREMENTAL_MATCH", "1") != "0"):
+            # the resident vocabulary is exactly the one this prune started from: carry the matches over
+            engine.set_vocab_pruned(flat, off, ids, sage_model.max_len, pm[1])
+        else:
+            engine.set_vocab_packed(flat, off, ids, sage_model.max_len)
         engine.cache["vocab"] = (sage_model, tag)
 
 

@@ -32,6 +32,8 @@ class SaGeTokenizer:
         self._inv_str_vocab = None
         self._encoded: Dict[bytes, str] = {}    # HF-encoded form of every key seen so far (keys survive prunes)
         self._packed = None                 # (key bytes uint8, key offsets int64, ids int32): what the engine uploads
+        self.prune_map = None
+        self._id_space = 0
         self.vocab_version = 0      # bumped on every set_vocabulary; engines re-upload when it changes
         self.max_len = max_len
         self.set_vocabulary(initial_vocabulary)
@@ -48,6 +50,17 @@ class SaGeTokenizer:
     def set_vocabulary(self, new_vocab: Sequence[bytes]) -> None:
         table = self.set_bytes_vocab(new_vocab)
         require_all_single_bytes(table)
+        # A vocabulary that only lost keys (the builder's prune, SaGeVocabBuilder.py:159-192) is remembered as such: the
+        # engine then moves its resident matches instead of matching the corpus again (sage_set_vocab_pruned).
+        self.prune_map = None               # (version it applies to, old id -> new id or -1)
+        before = self.byte_vocab
+        if before is not None and len(table) <= len(before):
+            get = before.get
+            old_ids = np.fromiter((get(k, -1) for k in table), dtype=np.int64, count=len(table))
+            if old_ids.size and old_ids.min() >= 0:
+                o2n = np.full(self._id_space, -1, dtype=np.int32)
+                o2n[old_ids] = np.fromiter(table.values(), dtype=np.int32, count=len(table))
+                self.prune_map = (self.vocab_version, o2n)
         self.byte_vocab = table
         self.inv_byte_vocab = {i: k for k, i in table.items()}
         self._str_vocab = self._inv_str_vocab = None

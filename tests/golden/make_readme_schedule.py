@@ -10,8 +10,8 @@ stale rows of an older matrix after ids were re-compacted alternate with rounds 
 SaGeVocabBuilder.py:89-91,192), max_len 17 on a Turkish-style multi-byte corpus.
 
 Inputs (made here, never taken from the reference):
-  corpus      30,000 lines of `synth.make_corpus(style="tr")` (28.7 MB, ~3.5 M tokens); regenerated from its seed by the
-              test, sha256 pinned here.
+  corpus      240,000 short lines of `synth.make_corpus(style="tr", mean_log_words=2.2)` (28 MB, ~3.5 M tokens, 24 count
+              segments at 4 workers); regenerated from its seed by the test, sha256 pinned here.
   vocabulary  262,144 keys of which > 99 % are ACTIVE on that corpus, so that the first target (229,376) already forces
               a prune: frequency-ranked substrings (`synth.make_vocab`, 600,000 candidates), tokenized once, the 261,888
               most used multi-byte keys kept.  Stored in the fixture (sorted + front-coded); ids = 256 single bytes, then
@@ -53,7 +53,8 @@ from sage_tokenizer.paths import setSageFolder  # noqa: E402
 from sage_amd import synth  # noqa: E402
 
 SEED = synth.DEFAULT_SEED
-N_LINES = 30_000
+N_LINES = 240_000        # many SHORT lines: the reference gathers one numpy row object per distinct triple of a 10,000-line
+MEAN_LOG_WORDS = 2.2     # flush (utils.py:132-134): 7,500 lines of 950 bytes took 35 GB per worker here, 10,000 of 118 bytes take ~6
 MAX_LEN = 17
 V0 = 262_144
 SCHEDULE = [262144, 229376, 196608, 163840, 131072, 98304, 65536, 57344, 49152, 40960, 32768, 16384]   # README.md:11
@@ -64,7 +65,7 @@ N_CAND = 600_000
 N_TYPES = 1_000_000
 OUT_TAG = "readme_schedule"
 if os.environ.get("C3_SMALL"):      # dry run of this script at toy size (writes readme_schedule_small.*; not committed)
-    N_LINES, V0, N_CAND, N_TYPES, OUT_TAG = 1500, 4096, 9000, 20_000, "readme_schedule_small"
+    N_LINES, V0, N_CAND, N_TYPES, OUT_TAG = 6000, 4096, 9000, 20_000, "readme_schedule_small"
     SCHEDULE = [4096, 3584, 3072, 2560, 2048, 1536, 1024, 896, 768, 640, 512, 384]
     EMB_SCHEDULE = [4096, 2048, 1024, 768, 640, 512]
 
@@ -74,7 +75,7 @@ def sha(b: bytes) -> str:
 
 
 def make_inputs():
-    corpus, off = synth.make_corpus(N_LINES, seed=SEED + 301, style="tr", n_types=N_TYPES)
+    corpus, off = synth.make_corpus(N_LINES, seed=SEED + 301, style="tr", n_types=N_TYPES, mean_log_words=MEAN_LOG_WORDS)
     t0 = time.time()
     cand = synth.make_vocab(corpus, off, N_CAND, MAX_LEN, sample_bytes=len(corpus) + 1)
     print(f"{len(cand)} candidate keys in {time.time() - t0:.0f} s", flush=True)
@@ -118,7 +119,7 @@ def main():
     np.savez_compressed(HERE / f"{OUT_TAG}_vocab.npz", prefix_len=pre, suffix_len=suf, suffix_bytes=tail,
                         perm_seed=SEED + 302)
     print(f"inputs ready after {time.time() - t_all:.0f} s", flush=True)
-    rec = {"n_lines": N_LINES, "corpus_seed": SEED + 301, "style": "tr", "n_types": N_TYPES, "max_len": MAX_LEN,
+    rec = {"n_lines": N_LINES, "corpus_seed": SEED + 301, "style": "tr", "n_types": N_TYPES, "mean_log_words": MEAN_LOG_WORDS, "max_len": MAX_LEN,
            "schedule": SCHEDULE, "embeddings_schedule": EMB_SCHEDULE, "workers": WORKERS, "random_seed": SEED, "dim": 50,
            "corpus_sha256": sha(corpus.tobytes()),
            "vocab_sha256": sha(b"\n".join(v.hex().encode() for v in vocab)), "sample_every": SAMPLE_EVERY,

@@ -104,3 +104,75 @@ def test_two_rank_combine_equals_one_rank(tmp_path):
     c0, c1 = np.load(tmp_path / "corpus0.npz"), np.load(tmp_path / "corpus1.npz")
     assert np.array_equal(c0["data"], c1["data"]) and np.array_equal(c0["off"], c1["off"])
     assert bool(c0["wrote"]) and not bool(c1["wrote"])
+
+
+def _failing_rank_main(rank, world, port, out_dir):
+    sys.path.insert(0, str(REPO))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    from sage_amd.dist import StepBuffers, step_into
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class Engine:           # stands in for HipSage: rank 1's step fails like SAGE_E_ROW does (IndexError)
+        def ablation_step_device(self, bounds, d_loss, d_occ, d_tot, d_hist, pad=2):
+            if rank == 1:
+                raise IndexError("a token id is out of bounds for the embedding matrix")
+    buf = StepBuffers(8, 4, device=torch.device("cpu"))
+    outcome = "no exception"
+    try:
+        step_into(Engine(), np.array([0, 5]), buf, dist)
+    except IndexError as exc:
+        outcome = f"IndexError: {exc}"
+    (Path(out_dir) / f"outcome{rank}.txt").write_text(outcome)
+    # the group is still usable afterwards: nobody is stuck in a collective
+    step_into(type("Ok", (), {"ablation_step_device": lambda *a, **k: None})(), np.array([0, 5]), buf, dist)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_failing_rank_fails_every_rank(tmp_path):
+    """utils.py:167: a worker's exception surfaces in the parent.  Here: one rank's step raises, and every rank raises
+    the same class instead of waiting forever in the combine."""
+    import torch.multiprocessing as mp
+    mp.spawn(_failing_rank_main, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    o0, o1 = (tmp_path / "outcome0.txt").read_text(), (tmp_path / "outcome1.txt").read_text()
+    assert o1 == "IndexError: a token id is out of bounds for the embedding matrix"
+    assert o0.startswith("IndexError: the ablation step failed on rank 1 (IndexError)")
+
+
+def _ragged_corpus_rank_main(rank, world, port, out_dir):
+    sys.path.insert(0, str(REPO))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import random
+    import torch.distributed as dist
+    from sage_amd import hostio, setSageFolder
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    root = Path(out_dir)
+    setSageFolder(root / f"sage_rank{rank}")
+    random.seed(7)
+    # the source's last line has no newline and the shuffle moves it into the middle of the kept lines; the partial
+    # corpus file is named explicitly and shared by the ranks, and does not exist yet
+    part = hostio.load_corpus_for_rank(root / "ragged.txt", str(root / "partial.txt"), 1, rank)
+    np.savez(root / f"ragged{rank}.npz", data=part.data, off=part.offsets)
+    dist.barrier()
+    random.seed(7)
+    again = hostio.load_corpus_for_rank(root / "ragged.txt", str(root / "partial.txt"), 1, rank)    # now it exists: all reuse it
+    np.savez(root / f"ragged_again{rank}.npz", data=again.data, off=again.offsets)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_agree_on_a_corpus_without_final_newline(tmp_path):
+    import torch.multiprocessing as mp
+    lines = [f"line {i} of the source\n".encode() for i in range(40)]
+    lines[-1] = b"the last line has no newline"
+    (tmp_path / "ragged.txt").write_bytes(b"".join(lines))
+    mp.spawn(_ragged_corpus_rank_main, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "ragged0.npz"), np.load(tmp_path / "ragged1.npz")
+    assert np.array_equal(a["data"], b["data"]) and np.array_equal(a["off"], b["off"]) and len(a["off"]) == 41
+    pos = bytes(a["data"]).index(b"the last line has no newline")
+    assert pos + 28 < len(a["data"])          # the shuffle did move it off the end (else the test shows nothing)
+    a2, b2 = np.load(tmp_path / "ragged_again0.npz"), np.load(tmp_path / "ragged_again1.npz")
+    assert np.array_equal(a2["data"], b2["data"]) and np.array_equal(a2["off"], b2["off"])
+    assert len(a2["off"]) == 40               # the reference's reload quirk (two lines merged), the same on every rank

@@ -78,6 +78,45 @@ def test_two_ranks_run_the_hip_step_and_match_the_reference(tmp_path, packed):
     assert 0 < int(r0["resident"]) < n_lines and int(r0["resident"]) + int(r1["resident"]) == n_lines
 
 
+def _rank_fail_main(rank, world, port, out_dir):
+    sys.path.insert(0, str(REPO))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sage_amd import SaGeTokenizer
+    from sage_amd.dist import run_sage_distributed
+    from sage_amd.parallel import PackedCorpus
+    g, vocab, emb = _golden_inputs()
+    model = SaGeTokenizer(vocab, int(g["max_len"]))
+    corpus = PackedCorpus(g["line_bytes"], g["line_off"])
+    outcome = "no exception"
+    try:
+        run_sage_distributed(emb[:300] if rank == 1 else emb, corpus, model, WORKERS)     # rank 1: matrix too short
+    except IndexError as exc:
+        outcome = f"IndexError: {exc}"
+    (Path(out_dir) / f"outcome{rank}.txt").write_text(outcome)
+    tt, ttr, _, _ = run_sage_distributed(emb, corpus, model, WORKERS)      # the group still works afterwards
+    (Path(out_dir) / f"after{rank}.txt").write_text(f"{tt} {ttr}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_rank_whose_step_fails_fails_every_rank(tmp_path):
+    """utils.py:167 (`res.get()` re-raises a worker's exception in the parent): rank 1's embedding matrix is too short,
+    its HIP step ends in SAGE_E_ROW (numpy's IndexError in the reference, utils.py:133); rank 0 must raise too instead
+    of waiting in the combine, and the next step must work."""
+    import torch.multiprocessing as mp
+    g, _, _ = _golden_inputs()
+    mp.spawn(_rank_fail_main, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    o0, o1 = (tmp_path / "outcome0.txt").read_text(), (tmp_path / "outcome1.txt").read_text()
+    assert o1.startswith("IndexError: a token id is out of bounds")
+    assert o0.startswith("IndexError: the ablation step failed on rank 1 (IndexError)")
+    want = f"{int(g[f'w{WORKERS}_total_tokens'])} {int(g[f'w{WORKERS}_total_triples'])}"
+    assert (tmp_path / "after0.txt").read_text() == want == (tmp_path / "after1.txt").read_text()
+
+
 def test_distributed_entry_point_without_a_process_group():
     """run_sage_distributed on one rank (no process group) is run_sage_parallel."""
     from sage_amd import SaGeTokenizer, synth

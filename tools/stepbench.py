@@ -21,7 +21,9 @@ b = segment_line_bounds(N, 4)
 for _ in range(3): r = e.ablation_step(b)     # warm-up: the first steps on a fresh box run at ramping clocks
 e.set_profiling(True); e.reset_kernel_times()
 R = 5
-for _ in range(R): r = e.ablation_step(b)
+for _ in range(R):
+    if not os.environ.get('SB_WARM_MATCHES'): e.invalidate_matches()     # every step a cold one (matcher included)
+    r = e.ablation_step(b)
 kt = e.kernel_times()
 print("tokens", r[2], "triples", r[3], {k: round(v[0] / R, 3) for k, v in kt.items() if v[0] > 0}, "sum", round(sum(v[0] for v in kt.values()) / R, 2),
       "launches/step", {k: v[1] / R for k, v in kt.items() if k in ("partition", "count", "match")}, flush=True)
