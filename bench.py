@@ -45,16 +45,24 @@ CLASS_BOUND = {"match": "l2-miss-traffic", "score": "row-gather-latency", "pairs
                "count": "hbm", "partition": "hbm", "describe": "lds-latency", "logsig": "hbm", "walk": "latency"}
 
 
+def workload_tag(args):
+    """Names the workload in the file names under profiles/ (a PMC pass belongs to ONE workload)."""
+    lines = f"{args.lines // 1_000_000}m" if args.lines % 1_000_000 == 0 else f"{args.lines // 1000}k"
+    return f"{args.style}{args.max_len}_{lines}_d{args.dim}_v{args.vocab // 1024}k"
+
+
 def pmc_traffic(kernel_class, args):
-    """HBM-side bytes per launch of a kernel from the newest committed PMC passes (profiles/collect.sh: FETCH_SIZE and
-    WRITE_SIZE in runs of their own): raw, with FETCH_SIZE doubled (MI355X_MICROARCH.md: right for 16-B-per-lane
-    streaming reads) and with the factor profiles/*_pmc_calibration.json measured for the kernel's own access shape.
-    Only valid for the default workload the passes were taken on; else None."""
-    if (args.lines, args.vocab, args.dim, args.max_len, args.style) != (1_000_000, 262_144, 50, 16, "en"):
-        return None
+    """HBM-side bytes per launch of a kernel from the newest committed PMC passes OF THIS WORKLOAD (profiles/collect.sh
+    takes FETCH_SIZE and WRITE_SIZE in runs of their own and names its outputs after `workload_tag`): raw, with
+    FETCH_SIZE doubled (MI355X_MICROARCH.md: gfx950 counts 64 B per 128-B request) and `calibrated` = what
+    profiles/r02_pmc_calibration.json measured for this library's access shapes (the same factor 2.00).  None when no
+    pass of this workload is committed."""
     def version_key(path):   # r02_v3 after r01_v15: numbers compared as numbers
-        return [int(x) for x in re.findall(r"\d+", path.name)]
-    files = sorted((REPO / "profiles").glob("r*_pmc_traffic.json"), key=version_key)
+        return [int(x) for x in re.findall(r"\d+", path.name.split("_pmc_")[0].replace(workload_tag(args), ""))]
+    files = sorted((REPO / "profiles").glob(f"r*_{workload_tag(args)}_pmc_traffic.json"), key=version_key)
+    if not files and (args.lines, args.vocab, args.dim, args.max_len, args.style) == (1_000_000, 262_144, 50, 16, "en"):
+        files = sorted((p for p in (REPO / "profiles").glob("r*_v*_pmc_traffic.json") if re.fullmatch(r"r\d+_v\d+_pmc_traffic\.json", p.name)),
+                       key=lambda p: [int(x) for x in re.findall(r"\d+", p.name)])       # rounds 1-2 named the default workload's passes r0N_vM
     if not files:
         return None
     want = "__step_total__" if kernel_class == "__step_total__" else CLASS_KERNEL.get(kernel_class)
@@ -68,7 +76,7 @@ def pmc_traffic(kernel_class, args):
     return None
 
 
-def roofline_object(dom, achieved, avg_ms, launches_per_step, per_kernel_bytes, eb, args):
+def roofline_object(dom, achieved, avg_ms, launches_per_step, per_kernel_bytes, eb, args, compulsory=None):
     """The contract's roofline object for the kernel with the largest share of the step.  Besides the algorithmic rate it
     carries the MEASURED L2-miss-side rate (PMC bytes of the committed pass over the live launch time): for the gather
     and probe kernels that is the number to hold against the 8 TB/s peak, because their algorithmic bytes are partly
@@ -86,6 +94,12 @@ def roofline_object(dom, achieved, avg_ms, launches_per_step, per_kernel_bytes, 
     if traffic and avg_ms:
         out["traffic_GBs"] = traffic["fetch_x2"] / 1e9 / (avg_ms * 1e-3)
         out["traffic_frac"] = out["traffic_GBs"] / HBM_PEAK_GBS
+    if compulsory and dom in compulsory and avg_ms:
+        # a gather kernel's algorithmic bytes count a row every time a window names it; the compulsory bytes count it once
+        # per window of 32 consecutive occurrences (what the kernel keeps in flight): <= algorithmic by construction
+        cb = compulsory[dom] / launches_per_step
+        out["compulsory_bytes_per_launch"] = cb
+        out["frac_compulsory"] = cb / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     return out
 
 
@@ -104,7 +118,10 @@ def parse():
     ap.add_argument("--batch-mb", type=int, default=0)
     ap.add_argument("--score-mode", type=int, default=0, help="0 = float32 row storage where lossless, 1 = float64 storage")
     ap.add_argument("--match-mode", type=int, default=-1, help="matcher variant (development switch)")
-    ap.add_argument("--no-api-timing", action="store_true", help="skip the run_sage_parallel_ms measurement")
+    ap.add_argument("--no-api-timing", action="store_true", help="skip the run_sage_parallel_ms and step_after_prune measurements")
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
+                    help="N>1: weak = every rank holds its own --lines shard; strong = ONE --lines corpus cut over the ranks by "
+                         "the product's own sharding (partition_segments + sync_corpus_shard)")
     return ap.parse_args()
 
 
@@ -134,9 +151,14 @@ def log(msg):
 
 def algorithmic_bytes(st, dim):
     """Per step and rank, per kernel class: the bytes the algorithm has to move (Kernels, states each).
-    e = bytes per stored embedding element on the main pass (4: the lossless float32 copy)."""
+    e = bytes per stored embedding element on the main pass (4: the lossless float32 copy).  With float32 row storage the
+    occurrences are split: the score kernel runs on the EXACT list only (its window rows, its descriptors), the mixed
+    float64 kernel ("fix") on the rest, gathering marked rows from the float64 matrix and the others from the copy."""
     e = st["emb_elem_bytes"]
     tok, occ, nb = st["tokens"], st["occurrences"], st["corpus_bytes"]
+    occ_fix, rows_fix, rows_f64 = st["f64_fix_occurrences"], st["window_rows_inexact"], st["f64_rows_gathered"]
+    if e == 8:        # float64 storage: one score kernel over everything
+        occ_fix = rows_fix = rows_f64 = 0
     return {
         "match": nb * (1 + 1 + 8),                              # text + rem read, 8-byte match entry written, per byte
         "walk": tok * 8 * 2 + tok * 12,                         # M entry of every token read by both passes; token arrays out
@@ -144,10 +166,25 @@ def algorithmic_bytes(st, dim):
         "partition": occ * 64 + st["pairs"] * 8,                # descriptors in, one 8-byte record per position pair out
         "count": st["pairs"] * 8,                               # every record read once
         "pairs": tok * (dim * e + 16),                          # one row per token, 16-byte pair-cache entry out
-        "score": st["window_rows"] * dim * e + occ * 64,        # the rows of the ablated windows only + descriptors
+        "score": (st["window_rows"] - rows_fix) * dim * e + (occ - occ_fix) * 64,   # rows of the exact list's windows + descriptors
         "logsig": st["window_pairs"] * 8 + occ * (16 + 32),     # dots read once; header + pair-cache window per occurrence
-        "fix": st["f64_fix_occurrences"] * (st["window_rows"] / max(1, occ) * dim * 8 + 64),
+        "fix": (rows_fix - rows_f64) * dim * 4 + rows_f64 * dim * 8 + occ_fix * 64,
     }
+
+
+def compulsory_bytes(st, uniq, dim):
+    """The gather kernels' bytes when a row is counted ONCE per window of 32 consecutive occurrences
+    (sage_measure_unique_rows over the last batch, scaled to the step by occurrences)."""
+    if not uniq or uniq["occurrences"] <= 0:
+        return None
+    scale = st["occurrences"] / uniq["occurrences"]
+    e = st["emb_elem_bytes"]
+    occ_fix = st["f64_fix_occurrences"] if e == 4 else 0
+    out = {"score": uniq["exact_unique_rows"] * scale * dim * e + (st["occurrences"] - occ_fix) * 64}
+    if occ_fix:
+        share64 = st["f64_rows_gathered"] / max(1, st["window_rows_inexact"])
+        out["fix"] = uniq["inexact_unique_rows"] * scale * dim * (4 + 4 * share64) + occ_fix * 64
+    return out
 
 
 def main():
@@ -185,12 +222,12 @@ def main():
     log(f"rank {rank}/{world}: generating vocabulary sample")
     head, head_off = synth.make_corpus(head_lines, seed=seed, style=args.style, n_types=n_types)
     vocab = synth.make_vocab(head, head_off, args.vocab, args.max_len, sample_bytes=6_000_000)
-    if rank == 0 and args.lines == head_lines:
+    if (rank == 0 or args.scaling == "strong") and args.lines == head_lines:
         corpus, offsets = head, head_off
     else:
         log(f"vocabulary of {len(vocab)} keys built; generating {args.lines} lines")
-        corpus, offsets = synth.make_corpus(args.lines, seed=seed, line_seed=rank, style=args.style, n_types=n_types,
-                                            progress=log)
+        corpus, offsets = synth.make_corpus(args.lines, seed=seed, line_seed=0 if args.scaling == "strong" else rank,
+                                            style=args.style, n_types=n_types, progress=log)
     log(f"corpus: {len(corpus)} bytes")
     gen_s = time.time() - t_gen
 
@@ -205,12 +242,18 @@ def main():
     eng.set_score_mode(args.score_mode)
     t_up = time.time()
     parallel.sync_vocab(eng, model)
-    parallel.sync_corpus(eng, packed)
+    bounds = segment_line_bounds(len(offsets) - 1, args.workers)
+    strong = world > 1 and args.scaling == "strong"
+    if strong:      # the product's sharding: whole count segments balanced by bytes, only this rank's lines uploaded
+        bounds = parallel.sync_corpus_shard(eng, packed, bounds, rank, world)
+        log(f"rank {rank}: {len(bounds) - 1} count segments, {eng.n_lines} lines resident")
+    else:
+        parallel.sync_corpus(eng, packed)
     # Embeddings as train_embeddings leaves them (embeddings.py:77-89): float32 word2vec vectors for the tokens the
     # tokenized corpus contains (word2vec is trained on that very tokenization, min_count=1), the float64 uniform
     # draw for the rest.  The corpus is tokenized here on the GPU; with several ranks the token counts are summed so
     # that every rank builds the same matrix.
-    seen_counts = np.bincount(eng.tokenize(0, len(offsets) - 1)[0], minlength=len(vocab)).astype(np.int64)
+    seen_counts = np.bincount(eng.tokenize(0, eng.n_lines)[0], minlength=len(vocab)).astype(np.int64)
     if world > 1:
         t = torch.from_numpy(seen_counts).cuda()
         all_reduce_(t)
@@ -221,11 +264,11 @@ def main():
     parallel.sync_embeddings(eng, emb)
     upload_s = time.time() - t_up
     log(f"uploaded in {upload_s:.1f} s")
-    bounds = segment_line_bounds(len(offsets) - 1, args.workers)
     V = model.id_space()
     buf = StepBuffers(V, eng.hist_len)
 
     def step():   # the product's per-step path: sage_ablation_step_device into torch CUDA tensors + combine
+        eng.invalidate_matches()      # a COLD step: the matcher runs, whatever match table an earlier step left resident
         step_into(eng, bounds, buf, dist if world > 1 else None)
 
     def fence():
@@ -255,12 +298,15 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     st = eng.step_stats()                      # this rank's shard (taken before the API timing below runs more steps)
     kt = eng.kernel_times()
+    uniq = eng.measure_unique_rows(32)         # over the descriptors the last timed step left resident
+    loss_h, occ_h = buf.loss.cpu().numpy(), buf.occ.cpu().numpy()
 
     api_ms, api_parts = None, None
     if world == 1 and not args.no_api_timing:
         # SURVEY.md 8d's call: run_sage_parallel right after the prune loop's set_vocabulary (SaGeVocabBuilder.py:192),
         # i.e. vocabulary table rebuild + upload, the step, and the result dicts.  Corpus and embeddings stay resident.
         reps = []
+        os.environ["SAGE_INCREMENTAL_MATCH"] = "0"    # a cold call: tables rebuilt, matcher run (the carried-over case is below)
         for _ in range(3):
             model.set_vocabulary(vocab)           # bumps vocab_version: the next call re-uploads the table
             torch.cuda.synchronize()
@@ -270,10 +316,54 @@ def main():
             tt_api, ttr_api, losses_api, sizes_api = parallel.run_sage_parallel(emb, packed, model, args.workers)
             tc = time.perf_counter()
             reps.append(((tc - ta) * 1e3, (tb - ta) * 1e3))
+        os.environ.pop("SAGE_INCREMENTAL_MATCH", None)
         assert (tt_api, ttr_api) == (total_tokens, total_triples)
         api_ms, vocab_ms = sorted(reps)[1]
         api_parts = {"vocabulary_upload_ms": vocab_ms, "step_and_dicts_ms": api_ms - vocab_ms}
         log(f"run_sage_parallel after set_vocabulary: {reps} ms (total, of which vocabulary upload)")
+
+    after_prune = None
+    if world == 1 and not args.no_api_timing:
+        # The step AFTER a prune (every step of a schedule but the first): SaGe's own cut on the losses just computed
+        # (SaGeVocabBuilder.py:109-159: bytes protected, the lowest-loss ids go) down to 7/8 of the vocabulary, i.e. the
+        # README's 262144 -> 229376.  The pruned vocabulary only lost keys, so the resident match table is moved
+        # (sage_set_vocab_pruned) and the step launches no matcher; the same step with the table recomputed is timed
+        # beside it.  Reported separately: `value` above is the cold step.
+        scored = {int(i): float(loss_h[i]) for i in np.nonzero(occ_h)[0]}
+        model.add_all_byte_ids(scored, score=1e6)
+        # the README schedule scaled to this vocabulary; targets the active vocabulary already meets are skipped
+        # (SaGeVocabBuilder.py:130-136) -- on the default corpus 208k of the 262,144 keys are active, so the cut is 196,608
+        readme = [262144, 229376, 196608, 163840, 131072, 98304, 65536, 57344, 49152, 40960, 32768, 16384]
+        target = next((t * len(vocab) // 262144 for t in readme[1:] if t * len(vocab) // 262144 < len(scored)), len(scored) - 1)
+        ranked = sorted((v, k) for k, v in scored.items())
+        doomed = {model.id_to_bytes(t) for _, t in ranked[:len(scored) - target]}
+        survivors = [k for k in vocab if k not in doomed]
+        res = {}
+        for mode, incr in (("carried_matches", "1"), ("rematched", "0")):
+            model.set_vocabulary(vocab)
+            parallel.sync_vocab(eng, model)
+            eng.invalidate_matches()
+            step_into(eng, bounds, buf, None)             # the step before the prune (leaves a complete match table)
+            os.environ["SAGE_INCREMENTAL_MATCH"] = incr
+            model.set_vocabulary(survivors)
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            parallel.sync_vocab(eng, model)
+            tb = time.perf_counter()
+            step_into(eng, bounds, buf, None)
+            torch.cuda.synchronize()
+            tc = time.perf_counter()
+            res[mode] = {"vocabulary_ms": (tb - ta) * 1e3, "step_ms": (tc - tb) * 1e3, "total_ms": (tc - ta) * 1e3,
+                         "no_matcher": eng.step_stats()["no_matcher"], "total_tokens": int(buf.tot[0].item()),
+                         "total_triples": int(buf.tot[1].item())}
+        os.environ.pop("SAGE_INCREMENTAL_MATCH", None)
+        assert res["carried_matches"]["no_matcher"] == 1 and res["rematched"]["no_matcher"] == 0
+        assert (res["carried_matches"]["total_tokens"], res["carried_matches"]["total_triples"]) == \
+               (res["rematched"]["total_tokens"], res["rematched"]["total_triples"])
+        after_prune = {"active_before": len(scored), "target": target, "pruned_keys": len(vocab) - len(survivors),
+                       "vocabulary_after": len(survivors), **res}
+        model.set_vocabulary(vocab)
+        log(f"step after a prune: {res}")
 
     if rank == 0:
         # ---- algorithmic bytes, statistics measured on this very corpus ----
@@ -307,22 +397,26 @@ def main():
             "ms_per_step": ms_per_step,
             "run_sage_parallel_ms": api_ms,
             "run_sage_parallel_parts": api_parts,
+            "step_after_prune_ms": after_prune["carried_matches"]["total_ms"] if after_prune else None,
+            "step_after_prune": after_prune,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {"embeddings": f"float32 word2vec-shaped rows upcast to float64, {int((~seen).sum())} float64 uniform rows (embeddings.py:77-89)",
-                       "workload": f"{args.lines}-line synthetic {args.style}-wiki-shaped corpus per GPU, single "
+                       "workload": f"{args.lines}-line synthetic {args.style}-wiki-shaped corpus {'cut over the GPUs' if strong else 'per GPU'}, single "
                                    f"{args.vocab}-key vocabulary ablation step (tokenize + score + counts), D={args.dim}, "
                                    f"max_len={args.max_len}, pad=2, workers_number={args.workers}",
                        "workload_shape": "substring-frequency vocabulary: ablations rejoin the base tokenization late, so this "
                                          "corpus is harder than the survey's measured text (b 5.3 / f_m 0.93 / r 7.3 / p 24.4); "
                                          "its own statistics are in step_roofline",
-                       "lines_per_gpu": args.lines, "vocab": len(vocab), "dim": args.dim, "max_len": args.max_len,
+                       "lines_per_gpu": int(eng.n_lines), "workload_tag": workload_tag(args), "vocab": len(vocab), "dim": args.dim, "max_len": args.max_len,
                        "corpus_bytes_per_gpu": int(st["corpus_bytes"]), "total_tokens": total_tokens,
                        "total_triples": total_triples},
-            "roofline": roofline_object(dom, achieved, avg_ms, launches_per_step, per_kernel_bytes, eb, args),
+            "roofline": roofline_object(dom, achieved, avg_ms, launches_per_step, per_kernel_bytes, eb, args,
+                                        compulsory_bytes(st, uniq, args.dim)),
+            "unique_rows_per_32_occurrences": uniq,
             "step_roofline": {"measured_hbm_bytes_per_step": pmc_traffic("__step_total__", args) if world == 1 else None,
                               "bytes_per_token_A": A_of(eb), "achieved_GBs_per_gpu": step_gbs(eb), "frac": step_gbs(eb) / HBM_PEAK_GBS,
                               "bytes_per_token_A_e8": A_of(8), "frac_e8": step_gbs(8) / HBM_PEAK_GBS,
@@ -332,11 +426,16 @@ def main():
                               "long_occurrence_share": st["long_occurrences"] / occ,
                               "f64_fix_occurrences": st["f64_fix_occurrences"]},
             "kernel_ms_per_step": {k: kt[k][0] / args.steps for k in kt},
+            "timing_note": "the timed region is K cold steps (sage_invalidate_matches before each: the matcher runs every step) "
+                           "between barrier + synchronize pairs; the per-kernel HIP events (sage_set_profiling) are recorded "
+                           "inside it, on the library's stream",
             # every kernel class against the HBM roofline: algorithmic bytes per step / its time per step
             "kernel_roofline": {k: {"algorithmic_GB_per_step": per_kernel_bytes[k] / 1e9, "bound": CLASS_BOUND.get(k),
                                     "GBps": per_kernel_bytes[k] / (kt[k][0] / args.steps * 1e-3) / 1e9 if kt[k][0] > 0 else 0.0,
                                     "frac": per_kernel_bytes[k] / (kt[k][0] / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS if kt[k][0] > 0 else 0.0}
                                 for k in per_kernel_bytes},
+            "kernel_frac_compulsory": {k: v / (kt[k][0] / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                       for k, v in (compulsory_bytes(st, uniq, args.dim) or {}).items() if kt[k][0] > 0},
             # the same kernels by MEASURED L2-miss-side bytes (committed PMC pass) over the live kernel time
             "kernel_traffic_GBps": {k: (lambda t: t["fetch_x2"] * (kt[k][1] / args.steps) / (kt[k][0] / args.steps * 1e-3) / 1e9
                                         if t and kt[k][0] > 0 else None)(pmc_traffic(k, args)) for k in per_kernel_bytes if k not in ("walk", "fix")},

@@ -216,9 +216,17 @@ int sage_train_embeddings(sage_ctx* ctx, int32_t dim, int32_t window, int32_t ne
  * counting pass, records per tile, records read against position pairs; expected 0 -- the tests hold it there),
  * out[14]=1 if total_triples of the last step came from the HBM sets (count mode 1 or a fallback) else 0,
  * out[15]=bit 0: the key buckets were sized by a counting pass (heavily repeated keys); bit 1: the step launched no matcher
- * (its match table was carried over a prune by sage_set_vocab_pruned). */
-#define SAGE_STEP_STATS 16
+ * (its match table was carried over a prune by sage_set_vocab_pruned); out[16]=window ids of the occurrences scored by the
+ * float64/mixed kernel (a subset of out[8]); out[17]=of those, rows gathered from the float64 matrix; out[18..23]=0. */
+#define SAGE_STEP_STATS 24
 int sage_get_step_stats(sage_ctx* ctx, int64_t* out /*[SAGE_STEP_STATS]*/);
+
+/* Measurement hook for bench.py's roofline (no counterpart in the reference): distinct embedding rows per window of
+ * `window` consecutive occurrences, over the LAST batch of the last step (its descriptors are still resident) -- the rows a
+ * gather kernel that keeps `window` occurrences in flight must fetch, i.e. its compulsory traffic.  out[0], out[1] =
+ * distinct rows and window ids of the occurrences on the exact list (all occurrences when the step had no float32/float64
+ * split), out[2], out[3] = the same for the inexact list, out[4] = occurrences of that batch, out[5] = batches of the step. */
+int sage_measure_unique_rows(sage_ctx* ctx, int32_t window, int64_t* out /*[6]*/);
 
 /* Test hook (no counterpart in the reference): runs the step's own exclusive scan over n copies of `value` and returns
  * the 64-bit grand total and the last (32-bit, wrapping) offset.  The step decides from the 64-bit total whether a batch's

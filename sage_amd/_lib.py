@@ -84,6 +84,8 @@ def load():
                                           C.c_int32, C.c_uint64, C.c_int64, C.POINTER(C.c_double), pi64]
     lib.sage_get_step_stats.restype = C.c_int
     lib.sage_get_step_stats.argtypes = [vp, pi64]
+    lib.sage_measure_unique_rows.restype = C.c_int
+    lib.sage_measure_unique_rows.argtypes = [vp, C.c_int32, pi64]
     lib.sage_debug_scan_total.restype = C.c_int
     lib.sage_debug_scan_total.argtypes = [vp, C.c_uint32, i64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
     _lib = lib
@@ -93,7 +95,7 @@ def load():
 EXPORTED = ["sage_version", "sage_create", "sage_destroy", "sage_last_error", "sage_set_vocab", "sage_set_vocab_pruned", "sage_set_corpus",
             "sage_set_embeddings", "sage_tokenize", "sage_tokenize_noalloc", "sage_ablation_step", "sage_ablation_step_device",
             "sage_set_profiling", "sage_reset_kernel_times", "sage_get_kernel_times", "sage_set_batch_bytes",
-            "sage_set_match_mode", "sage_invalidate_matches", "sage_set_count_mode", "sage_set_score_mode", "sage_set_deterministic", "sage_train_embeddings", "sage_get_step_stats", "sage_debug_scan_total"]
+            "sage_set_match_mode", "sage_invalidate_matches", "sage_set_count_mode", "sage_set_score_mode", "sage_set_deterministic", "sage_train_embeddings", "sage_get_step_stats", "sage_debug_scan_total", "sage_measure_unique_rows"]
 
 
 class HipSage:
@@ -290,11 +292,18 @@ class HipSage:
         return total.value, last.value
 
     def step_stats(self):
-        out = np.zeros(16, dtype=np.int64)
+        out = np.zeros(24, dtype=np.int64)
         self._check(self._lib.sage_get_step_stats(self._h, _ptr(out, C.c_int64)))
         return {"tokens": int(out[0]), "corpus_bytes": int(out[1]), "occurrences": int(out[2]),
                 "rows": int(out[3]), "records": int(out[4]), "pairs": int(out[5]), "emb_elem_bytes": int(out[6]),
                 "f64_fix_occurrences": int(out[7]), "window_rows": int(out[8]), "long_occurrences": int(out[9]),
                 "dim": int(out[10]), "padded_dim": int(out[11]), "window_pairs": int(out[12]),
                 "count_redos": int(out[13]), "count_from_hbm_sets": int(out[14]), "exact_buckets": int(out[15]) & 1,
-                "no_matcher": (int(out[15]) >> 1) & 1}
+                "no_matcher": (int(out[15]) >> 1) & 1, "window_rows_inexact": int(out[16]), "f64_rows_gathered": int(out[17])}
+
+    def measure_unique_rows(self, window: int = 32):
+        """Distinct rows per `window` consecutive occurrences over the last batch of the last step (sage_measure_unique_rows)."""
+        out = np.zeros(6, dtype=np.int64)
+        self._check(self._lib.sage_measure_unique_rows(self._h, int(window), _ptr(out, C.c_int64)))
+        return {"exact_unique_rows": int(out[0]), "exact_window_ids": int(out[1]), "inexact_unique_rows": int(out[2]),
+                "inexact_window_ids": int(out[3]), "occurrences": int(out[4]), "batches": int(out[5])}

@@ -121,6 +121,9 @@ struct sage_ctx {
     uint64_t pair_limit = 0xFFFFFF00ull;   // 32-bit pair / dot offsets per batch (SAGE_TEST_PAIR_LIMIT lowers it: test hook)
     int64_t batch_bytes = 512ll << 20;   // fewer, larger batches: the line walks last as long as a batch's longest line (4.9 -> 3.9 ms from two batches to one)
     int set_factor = 16;
+    uint32_t last_n_occ = 0;       // the last batch of the last step: what sage_measure_unique_rows looks at
+    bool last_split = false;
+    int last_batches = 0;
 
     // measurement
     bool profiling = false;
@@ -396,7 +399,7 @@ void launch_dots_mixed(sage_ctx* c, uint32_t n_occ) {
     k_dots_mixed<G, EPL, 5><<<grid, 256, 0, c->stream>>>(
         c->desc.as<uint4>(), c->pool.as<uint32_t>(), n_occ, c->dot_off.as<uint32_t>(), c->emb.as<double>(), (uint32_t)c->emb_rows,
         (uint32_t)c->dp, c->dots.as<double>(), c->flags.as<uint32_t>(), c->inex_list.as<uint32_t>(), c->inex_count.as<uint32_t>(),
-        c->emb32.as<float>(), c->inexact.as<uint32_t>());
+        c->emb32.as<float>(), c->inexact.as<uint32_t>(), c->stats.as<unsigned long long>());
 }
 
 // instantiation per padded row width: float32 rows are whole 16-byte loads of 4 elements, float64 rows of 2
@@ -487,6 +490,7 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
         HIP_TRY(c, hipMemsetAsync(c->stats.p, 0, STAT_COUNT * 8, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->flags.p, 0, FLAG_COUNT * 4, c->stream));
         uint64_t total_tokens = 0, total_bytes = 0, total_occ = 0;
+        int n_batches = 0;
 
         int64_t sa = 0;
         bool shrink = false;
@@ -752,6 +756,7 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
             }
             if ((rc = ensure(c, c->dots, std::max<uint64_t>(n_dots, 1) * 8))) return rc;
             launch_score(c, A.tok_w0, n_tok, n_occ);
+            c->last_n_occ = n_occ; c->last_split = split; ++n_batches;
             HIP_TRY(c, hipGetLastError());
             sa = sb;
         }
@@ -808,6 +813,7 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
         }
         if (flags[FLAG_ROW_OOB])
             return fail(c, SAGE_E_ROW, "a token id is out of bounds for the embedding matrix");
+        c->last_batches = n_batches;
         const bool ran_without_matcher = c->m_valid;
         if (c->m_valid) ++c->steps_without_matcher;
         else if (c->m_whole && n_seg > 0 && bounds[0] == 0 && bounds[n_seg] == c->n_lines) c->m_valid = true;   // every line was matched
@@ -826,6 +832,8 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
         c->step_stats[10] = (int64_t)c->dim;
         c->step_stats[11] = (int64_t)c->dp;
         c->step_stats[12] = (int64_t)stats[STAT_ABPAIRS];
+        c->step_stats[16] = (int64_t)stats[STAT_WROWS_INEXACT];
+        c->step_stats[17] = (int64_t)stats[STAT_MARKED_ROWS];
         c->step_stats[13] = c->count_redos;
         c->step_stats[14] = (c->count_mode == 1 || c->count_fallback) ? 1 : 0;   // which back end produced total_triples
         c->step_stats[15] = (c->exact_buckets ? 1 : 0) | (ran_without_matcher ? 2 : 0);
@@ -1501,6 +1509,29 @@ int sage_debug_scan_total(sage_ctx* c, uint32_t value, int64_t n, uint64_t* out_
     HIP_TRY(c, hipMemcpyAsync(out_last, c->pair_off.as<uint32_t>() + n, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     collect_events(c);
+    return SAGE_OK;
+}
+
+int sage_measure_unique_rows(sage_ctx* c, int32_t window, int64_t* out) {
+    if (!c || !out || window < 1 || window > 4096) return fail(c, SAGE_E_ARG, "bad argument");
+    if (c->last_n_occ == 0 || c->last_batches < 1) return fail(c, SAGE_E_STATE, "no step has run");
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure(c, c->tile_dbg, 64))) return rc;
+    unsigned long long h[4] = {0, 0, 0, 0};
+    for (int which = 0; which < 2; ++which) {      // 0: the exact list (or every occurrence), 1: the inexact list
+        if (which == 1 && !c->last_split) break;
+        HIP_TRY(c, hipMemsetAsync(c->tile_dbg.p, 0, 16, c->stream));
+        const uint32_t* list = !c->last_split ? nullptr : which == 0 ? c->exact_list.as<uint32_t>() : c->inex_list.as<uint32_t>();
+        const uint32_t* cnt = !c->last_split ? nullptr : which == 0 ? c->exact_count.as<uint32_t>() : c->inex_count.as<uint32_t>();
+        k_unique_rows<<<(uint32_t)c->n_cu * 4u, 256, 0, c->stream>>>(c->desc.as<uint4>(), c->pool.as<uint32_t>(), list, cnt, c->last_n_occ,
+                                                                    (uint32_t)window, c->tile_dbg.as<unsigned long long>());
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipMemcpyAsync(h + 2 * which, c->tile_dbg.p, 16, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    out[0] = (int64_t)h[0]; out[1] = (int64_t)h[1]; out[2] = (int64_t)h[2]; out[3] = (int64_t)h[3];
+    out[4] = (int64_t)c->last_n_occ; out[5] = c->last_batches;
     return SAGE_OK;
 }
 

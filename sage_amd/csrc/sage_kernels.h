@@ -33,6 +33,8 @@ enum { FLAG_SET_OVERFLOW = 0, FLAG_ROW_OOB = 1, FLAG_EMPTY_LINE = 2, FLAG_COUNT 
 enum { STAT_OCC = 0, STAT_ROWS = 1, STAT_PAIRS = 2, STAT_DISTINCT = 3, STAT_INEXACT = 4, STAT_WROWS = 5 /* ids of the ablated windows: the rows k_dots gathers */,
        STAT_LONG = 6 /* occurrences whose window went to the id pool */, STAT_ABPAIRS = 7 /* position pairs of the ablated windows */,
        STAT_RECORDS = 8 /* key records the dedupe kernel read: must equal STAT_PAIRS, every record scattered and read once */,
+       STAT_WROWS_INEXACT = 9 /* window ids of the occurrences on the inexact list (scored by k_dots_mixed) */,
+       STAT_MARKED_ROWS = 10 /* of those, the rows k_dots_mixed gathered from the float64 matrix (marked in the bitmap) */,
        STAT_COUNT = 12 };
 
 // ----------------------------------------------------------------------------------------------------------
@@ -701,6 +703,10 @@ __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ 
         // branch); lanes that do not take part are masked through their candidate bits, not through EXEC.
         if constexpr (QUEUED) {
             uint2* q = mq_all + (tid >> 6) * MQ_CAP;
+#ifndef SAGE_MATCH_CLASSES
+#define SAGE_MATCH_CLASSES 5
+#endif
+#if SAGE_MATCH_CLASSES == 5
             if constexpr (ML >= 9) {
                 // (finer classes = more chances to stop early = fewer requests, up to a point: 13+, 9..12, 7..8, 5..6, 3..4
                 // measures 6.53 ms per 152 MB, 9+, 5..8, 3..4 6.77, one class per length 7.07)
@@ -710,6 +716,19 @@ __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ 
             probe_queued<NW, 7, 8, ML>(v, cand, fh, W, top, q, lane);
             probe_queued<NW, 5, 6, ML>(v, cand, fh, W, top, q, lane);
             probe_queued<NW, 3, 4, ML>(v, cand, fh, W, top, q, lane);
+#elif SAGE_MATCH_CLASSES == 3
+            if constexpr (ML >= 9) { if (__any((cand >> 8) != 0u)) probe_queued<NW, 9, ML, ML>(v, cand, fh, W, top, q, lane); }
+            probe_queued<NW, 5, (ML < 8 ? ML : 8), ML>(v, cand, fh, W, top, q, lane);
+            probe_queued<NW, 3, 4, ML>(v, cand, fh, W, top, q, lane);
+#elif SAGE_MATCH_CLASSES == 4
+            if constexpr (ML >= 11) { if (__any((cand >> 10) != 0u)) probe_queued<NW, 11, ML, ML>(v, cand, fh, W, top, q, lane); }
+            if constexpr (ML >= 7) probe_queued<NW, 7, (ML < 10 ? ML : 10), ML>(v, cand, fh, W, top, q, lane);
+            probe_queued<NW, 5, 6, ML>(v, cand, fh, W, top, q, lane);
+            probe_queued<NW, 3, 4, ML>(v, cand, fh, W, top, q, lane);
+#else
+            if constexpr (ML >= 7) { if (__any((cand >> 6) != 0u)) probe_queued<NW, 7, ML, ML>(v, cand, fh, W, top, q, lane); }
+            probe_queued<NW, 3, (ML < 6 ? ML : 6), ML>(v, cand, fh, W, top, q, lane);
+#endif
         } else {
             if constexpr (ML >= 9) probe_sparse<NW, 9, ML, ML>(v, cand, fh, W, top);
             const uint32_t c1 = top.m2 == 0u ? cand : 0u;

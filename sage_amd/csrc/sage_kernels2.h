@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
     if (threadIdx.x < SEG_LDS) lseg[threadIdx.x] = 0ull;
     for (uint32_t i = threadIdx.x; i < DESC_ACC; i += 256) { occ_id[i] = ACC_EMPTY; occ_n[i] = 0; }
     __syncthreads();
-    unsigned long long n_rows = 0, n_pairs = 0, n_wrows = 0, n_ab = 0;
+    unsigned long long n_rows = 0, n_pairs = 0, n_wrows = 0, n_ab = 0, n_wrows_bad = 0;
     const uint32_t n_items = LONG ? *D.long_count : n_occ;
     const uint32_t n_round = (n_items + 255u) & ~255u;
     uint32_t* my = rows + (LONG ? 0 : threadIdx.x * DESC_LDS_STRIDE);
@@ -371,6 +371,7 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
                 my_pairs = (unsigned long long)ab_pairs + window_pairs(w.pl, w.m, w.pr);
                 n_rows += L + w.m;
                 n_wrows += L;
+                n_wrows_bad += bad ? L : 0u;
                 n_ab += ab_pairs;
                 D.occ_a[o] = w.a | (w.pl << 20) | (w.pr << 22) | (min(w.m, SAGE_OCC_M_SEE_DESC) << 24) | (bad ? SAGE_OCC_INEXACT : 0u);
                 D.npairs_ab[o] = ab_pairs;
@@ -448,12 +449,14 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
         n_pairs += __shfl_down(n_pairs, d, 64);
         n_wrows += __shfl_down(n_wrows, d, 64);
         n_ab += __shfl_down(n_ab, d, 64);
+        n_wrows_bad += __shfl_down(n_wrows_bad, d, 64);
     }
     if (lane == 0) {
         if (n_rows) atomicAdd(&D.stats[STAT_ROWS], n_rows);
         if (n_pairs) atomicAdd(&D.stats[STAT_PAIRS], n_pairs);
         if (n_wrows) atomicAdd(&D.stats[STAT_WROWS], n_wrows);
         if (n_ab) atomicAdd(&D.stats[STAT_ABPAIRS], n_ab);
+        if (n_wrows_bad) atomicAdd(&D.stats[STAT_WROWS_INEXACT], n_wrows_bad);
     }
     if (LONG && blockIdx.x == 0 && threadIdx.x == 0 && n_items) atomicAdd(&D.stats[STAT_LONG], (unsigned long long)n_items);
 }
@@ -633,8 +636,10 @@ __device__ __forceinline__ void dots_body(const uint4* __restrict__ desc, const 
                                               double* __restrict__ dots, uint32_t* __restrict__ flags,
                                               const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count,
                                               const float* __restrict__ emb32 = nullptr,
-                                              const uint32_t* __restrict__ bitmap = nullptr) {
+                                              const uint32_t* __restrict__ bitmap = nullptr,
+                                              unsigned long long* __restrict__ stats = nullptr) {
     static_assert(!MIXED || std::is_same<T, double>::value, "MIXED is a variant of the float64 kernel");
+    uint32_t n_marked = 0;      // MIXED: rows this group took from the float64 matrix (a statistic for the byte model)
     // list != nullptr: only the *list_count occurrences on the list are processed (float64 fix-up pass of the float32
     // fast path)
     const uint32_t gl = threadIdx.x % G;
@@ -738,6 +743,7 @@ __device__ __forceinline__ void dots_body(const uint4* __restrict__ desc, const 
                     qm[NF - 1] |= 16u;                                       // bit4: the slice holds float32 bits
                 } else {
                     load_row_slice<G, EPL>(emb, rid, dp, gl, B[(s + NF) % NS]);
+                    n_marked += (rlive && gl == 0u) ? 1u : 0u;
                 }
             } else {
                 load_row_slice<G, EPL>(emb, rid, dp, gl, B[(s + NF) % NS]);
@@ -770,6 +776,11 @@ __device__ __forceinline__ void dots_body(const uint4* __restrict__ desc, const 
         }
     }
     if (gl < pend) dots[wr + gl] = mydot;
+    if constexpr (MIXED) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) n_marked += __shfl_down(n_marked, d, 64);
+        if ((threadIdx.x & 63u) == 0u && n_marked && stats) atomicAdd(&stats[STAT_MARKED_ROWS], (unsigned long long)n_marked);
+    }
 }
 
 template <int G, int EPL, typename T, int NS>
@@ -788,8 +799,64 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_dots_mixed(const uint4* __restrict__ desc, const uint32_t* __restrict__ pool, uint32_t n_occ,
                   const uint32_t* __restrict__ dot_off, const double* __restrict__ emb, uint32_t emb_rows, uint32_t dp,
                   double* __restrict__ dots, uint32_t* __restrict__ flags, const uint32_t* __restrict__ list,
-                  const uint32_t* __restrict__ list_count, const float* __restrict__ emb32, const uint32_t* __restrict__ bitmap) {
-    dots_body<G, EPL, double, NS, true>(desc, pool, n_occ, dot_off, emb, emb_rows, dp, dots, flags, list, list_count, emb32, bitmap);
+                  const uint32_t* __restrict__ list_count, const float* __restrict__ emb32, const uint32_t* __restrict__ bitmap,
+                  unsigned long long* __restrict__ stats) {
+    dots_body<G, EPL, double, NS, true>(desc, pool, n_occ, dot_off, emb, emb_rows, dp, dots, flags, list, list_count, emb32, bitmap, stats);
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// Measurement only (sage_measure_unique_rows): distinct embedding rows per window of `win` consecutive occurrences of a
+// list -- the rows a gather kernel with that much reuse in flight MUST fetch (k_dots hands its occurrences out in windows
+// of 32).  One wave per window; a per-wave LDS set with generation tags, so nothing is cleared between windows.  A
+// window with more ids than the set holds counts the excess as distinct (an upper bound; such windows are rare).
+// ----------------------------------------------------------------------------------------------------------
+#define UR_SLOTS 4096u
+__global__ __launch_bounds__(256) void k_unique_rows(const uint4* __restrict__ desc, const uint32_t* __restrict__ pool,
+                                                     const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count,
+                                                     uint32_t n_occ, uint32_t win, unsigned long long* __restrict__ out /*[2]: distinct, ids*/) {
+    __shared__ uint32_t set_all[4 * UR_SLOTS];
+    uint32_t* set = set_all + (threadIdx.x >> 6) * UR_SLOTS;
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t i = lane; i < UR_SLOTS; i += 64u) set[i] = 0u;
+    const uint32_t n = list ? *list_count : n_occ;
+    const uint32_t n_win = (n + win - 1u) / win;
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
+    unsigned long long distinct = 0, ids_seen = 0;
+    uint32_t gen = 0;
+    for (uint32_t w = wave; w < n_win; w += n_waves) {
+        gen = (gen + 1u) & 0xFFFu;
+        if (gen == 0u) { for (uint32_t i = lane; i < UR_SLOTS; i += 64u) set[i] = 0u; gen = 1u; }
+        __builtin_amdgcn_wave_barrier();
+        uint32_t filled = 0;
+        for (uint32_t i = w * win; i < min(n, (w + 1u) * win); ++i) {
+            const uint32_t o = list ? list[i] : i;
+            const uint4 h = desc[(size_t)o * 4];
+            const Win ww = win_decode(h.x, h.z, h.w);
+            const uint32_t* ids = ww.pooled ? pool + h.y : reinterpret_cast<const uint32_t*>(desc + (size_t)o * 4) + 1;
+            for (uint32_t j = lane; j < ww.L; j += 64u) {
+                const uint32_t id = ids[j] & SAGE_ID_MASK;
+                ++ids_seen;
+                if (filled > UR_SLOTS / 2u) { ++distinct; continue; }        // (wave-uniform: set nearly full)
+                const uint32_t want = id | (gen << 20);
+                uint32_t s = (id * 0x9E3779B1u) >> 20;                       // 12 bits
+                for (;;) {
+                    const uint32_t cur = set[s];
+                    if (cur == want) break;
+                    if ((cur >> 20) != gen) {
+                        const uint32_t old = atomicCAS(&set[s], cur, want);
+                        if (old == cur) { ++distinct; break; }
+                        if (old == want) break;
+                        continue;                                           // someone else took the slot: look again
+                    }
+                    s = (s + 1u) & (UR_SLOTS - 1u);
+                }
+            }
+            filled += ww.L;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { distinct += __shfl_down(distinct, d, 64); ids_seen += __shfl_down(ids_seen, d, 64); }
+    if (lane == 0u) { atomicAdd(&out[0], distinct); atomicAdd(&out[1], ids_seen); }
 }
 
 // ----------------------------------------------------------------------------------------------------------

@@ -20,3 +20,15 @@ def load_npz(name):
 def load_json_gz(name):
     with gzip.open(GOLDEN / name, "rt") as f:
         return json.load(f)
+
+
+def front_decode(prefix_len: np.ndarray, suffix_len: np.ndarray, suffix_bytes: np.ndarray):
+    """Keys of a sorted, front-coded list (tests/golden/make_readme_schedule.py): key i = the first prefix_len[i] bytes of
+    key i-1 followed by its own suffix."""
+    raw = suffix_bytes.tobytes()
+    out, last, at = [], b"", 0
+    for p, n in zip(prefix_len.tolist(), suffix_len.tolist()):
+        last = last[:p] + raw[at:at + n]
+        at += n
+        out.append(last)
+    return out

@@ -1,25 +1,26 @@
 """GPU: the BASELINE.json workloads at full single-GPU size, checked through properties that need no oracle at this
 size.  configs[1]: 1,000,000 English lines, 262,144 keys, D=50, max_len=16, workers_number=4 (what bench.py times);
-configs[3]'s shape: Turkish-style multi-byte corpus, max_len 17, 1,000,000 lines (0.95 GB; the 5M-line run is a bench
-line); configs[4]'s shape: D=300 on the English corpus.  Properties: the step over all count segments is
-the sum of the steps over two halves (integers exact, losses to 1e-9), an independent distinct-count back end
-(per-segment HBM sets, count mode 1) and the unfiltered matcher give the same integers, float64 row storage gives the
-same losses as the float32 copy, and the totals tie together.  On the English corpus total_tokens / total_triples are
-also pinned to what every build of this repository since v1 has produced (profiles/r01_v*_bench_full.json): a
-regression pin, NOT an oracle value -- the oracle pins the algorithm at small sizes (tests/test_gpu_parity.py), this
-pins the large-size plumbing (batches, 32-bit offsets, bucket sizing).  D does not enter the integers, so the D=300
-run must reproduce the same pins."""
+configs[3] (C4) at its size: Turkish-style multi-byte corpus, max_len 17, 5,000,000 lines (4.38 GB, nine 512 MiB batches);
+configs[4] (C5) at its per-GPU size: D=300 on 2,500,000 English lines (a 20M-line corpus over 8 GPUs).  Properties: the
+step over all count segments is the sum of the steps over two halves (integers exact, losses to 1e-9), an independent
+distinct-count back end (per-segment HBM sets, count mode 1) and the unfiltered matcher give the same integers, float64
+row storage gives the same losses as the float32 copy, the partitioned count never fell back, and the totals tie
+together.  On the 1M-line English corpus total_tokens / total_triples are also pinned to what every build of this
+repository since v1 has produced (profiles/r01_v*_bench_full.json): a regression pin, NOT an oracle value -- the oracle
+pins the algorithm at small sizes (tests/test_gpu_parity.py), this pins the large-size plumbing (batches, 32-bit
+offsets, bucket sizing).  (make_corpus draws its lines chunk by chunk from one stream, so the 1M-line corpus is the
+head of the 2.5M-line one.)"""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
-N_LINES = 1_000_000
-PINNED = {"en": (86_193_104, 3_311_102_221)}
+PINNED = {("en", 1_000_000): (86_193_104, 3_311_102_221)}
+GENERATED = {"en": 2_500_000, "tr": 5_000_000}      # lines generated per style; smaller cases use the head
 _inputs = {}
 
 
-def _corpus_and_vocab(style, max_len):
+def _corpus_and_vocab(style, max_len, n_lines):
     from sage_amd import synth
     key = (style, max_len)
     if key not in _inputs:
@@ -27,17 +28,18 @@ def _corpus_and_vocab(style, max_len):
         seed = synth.DEFAULT_SEED
         head, head_off = synth.make_corpus(14_000, seed=seed, style=style, n_types=1_000_000)
         vocab = synth.make_vocab(head, head_off, 262_144, max_len, sample_bytes=6_000_000)
-        corpus, off = synth.make_corpus(N_LINES, seed=seed, style=style, n_types=1_000_000)
+        corpus, off = synth.make_corpus(GENERATED[style], seed=seed, style=style, n_types=1_000_000)
         _inputs[key] = (vocab, corpus, off)
-    return _inputs[key]
+    vocab, corpus, off = _inputs[key]
+    return vocab, corpus[:off[n_lines]], off[:n_lines + 1]
 
 
-@pytest.mark.parametrize("style,max_len,dim", [("en", 16, 50), ("en", 16, 300), ("tr", 17, 50)])
-def test_full_size_workload_properties(style, max_len, dim):
+@pytest.mark.parametrize("style,max_len,dim,N_LINES", [("en", 16, 50, 1_000_000), ("en", 16, 300, 2_500_000), ("tr", 17, 50, 5_000_000)])
+def test_full_size_workload_properties(style, max_len, dim, N_LINES):
     from sage_amd import synth
     from sage_amd._lib import HipSage
     from sage_amd.parallel import segment_line_bounds
-    vocab, corpus, off = _corpus_and_vocab(style, max_len)
+    vocab, corpus, off = _corpus_and_vocab(style, max_len, N_LINES)
     eng = HipSage(0)
     try:
         eng.set_vocab(vocab, None, max_len)
@@ -49,8 +51,8 @@ def test_full_size_workload_properties(style, max_len, dim):
         bounds = segment_line_bounds(N_LINES, 4)
         loss, occ, tt, ttr, hist = eng.ablation_step(bounds)
         assert tt == total == int(counts.sum()) == int(per_line.sum())
-        if style in PINNED:
-            assert (tt, ttr) == PINNED[style]
+        if (style, N_LINES) in PINNED:
+            assert (tt, ttr) == PINNED[(style, N_LINES)]
         assert int(hist.sum()) == int(occ.sum()) and np.isfinite(loss).all()
         assert not np.any((occ > 0) & (counts == 0))          # only tokens the tokenization produces are ablated
         multi = np.array([len(v) > 1 for v in vocab])
@@ -58,6 +60,7 @@ def test_full_size_workload_properties(style, max_len, dim):
         st = eng.step_stats()
         assert st["tokens"] == tt and st["occurrences"] == int(occ.sum()) and st["emb_elem_bytes"] == 4
         assert st["records"] == 2 * st["pairs"] and 0 < st["window_rows"] < st["rows"]
+        assert st["count_redos"] == 0 and st["count_from_hbm_sets"] == 0      # the partitioned count passed its own checks
         # halves add up (what sharding over GPUs relies on)
         n_seg = len(bounds) - 1
         mid = n_seg // 2

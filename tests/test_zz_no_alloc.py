@@ -73,3 +73,26 @@ def test_noalloc_tokenize_matches_tokenize_twice(style, max_len):
     finally:
         eng.close()
         other.close()
+
+
+@pytest.mark.parametrize("tag", ["en16", "tr17"])
+def test_noalloc_tokenize_against_the_reference_golden(tag):
+    """Independent of sage_tokenize: the (id, start, width) triples the REFERENCE's tokenize produced
+    (tests/golden/tokenize_<tag>.npz, model.py:81-101), including the edge-case lines (one byte, no newline, a key at the
+    line end, raw 0x00 0xff)."""
+    from sage_amd._lib import HipSage
+    from tests.golden_io import load_npz, unpack
+    g = load_npz(f"tokenize_{tag}.npz")
+    vocab = unpack(g["vocab_bytes"], g["vocab_off"])
+    eng = HipSage(0)
+    try:
+        eng.set_vocab(vocab, None, int(g["max_len"]))
+        for _ in range(2):              # twice: the second call meets the scratch array as the first one left it
+            total, (ids, starts, widths, counts) = _noalloc(eng, g["line_bytes"], g["line_off"], capacity=len(g["ids"]))
+            assert total == len(g["ids"])
+            assert counts.tolist() == g["counts"].tolist()
+            assert ids[:total].tolist() == g["ids"].tolist()
+            assert starts[:total].tolist() == g["starts"].tolist()
+            assert widths[:total].tolist() == g["widths"].tolist()
+    finally:
+        eng.close()
