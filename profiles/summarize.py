@@ -14,8 +14,10 @@ import shutil
 import sys
 from pathlib import Path
 
+# usage: summarize.py <tag> [<collect.sh out-name>]   e.g.  summarize.py r03_en16_1m_d50_v256k en16  (bench.py looks the
+# PMC file up as profiles/r*_<workload_tag>_pmc_traffic.json; the tag of the default workload is en16_1m_d50_v256k)
 tag = sys.argv[1]
-src = Path("gpurun_out/prof")
+src = Path("gpurun_out/prof" + (f"_{sys.argv[2]}" if len(sys.argv) > 2 else ""))
 dst = Path("profiles")
 shutil.copy(src / "kt/run_kernel_stats.csv", dst / f"{tag}_kernel_stats.csv")
 shutil.copy(src / "bench_full.json", dst / f"{tag}_bench_full.json")

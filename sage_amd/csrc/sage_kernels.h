@@ -600,18 +600,35 @@ __global__ __launch_bounds__(256) void k_build_remap(const int32_t* __restrict__
     remap[i] = (uint32_t)to | (L << 20);
 }
 
+__device__ __forceinline__ uint32_t remap_one(uint32_t m1, const uint32_t* __restrict__ remap, uint32_t n_old, bool& bad) {
+    const uint32_t id = SAGE_M_ID(m1);
+    const uint32_t r = id < n_old ? remap[id] : 0xFFFFFFFFu;
+    if (r == 0xFFFFFFFFu) { bad = true; return 1u << 20; }     // (flagged: the table is not used; the id stays in bounds)
+    const uint32_t nid = SAGE_M_ID(r), L = SAGE_M_LEN(r);
+    return L == 0u ? (nid | (m1 & 0xFFF00000u)) : (nid | (L << 20));      // a shorter match cannot end the line
+}
+// four positions per thread and iteration: two 16-byte loads, the eight table lookups in flight together, two 16-byte stores
 __global__ __launch_bounds__(256) void k_remap_matches(uint2* __restrict__ M, uint64_t n_pos, const uint32_t* __restrict__ remap,
                                                        uint32_t n_old, const uint32_t* __restrict__ parent_new,
                                                        uint32_t* __restrict__ flags) {
-    for (uint64_t p = (uint64_t)blockIdx.x * 256u + threadIdx.x; p < n_pos; p += (uint64_t)gridDim.x * 256u) {
-        const uint32_t m1 = M[p].x;
-        const uint32_t id = SAGE_M_ID(m1);
-        const uint32_t r = id < n_old ? remap[id] : 0xFFFFFFFFu;
-        if (r == 0xFFFFFFFFu) { flags[FLAG_SET_OVERFLOW] = 1; continue; }
-        const uint32_t nid = SAGE_M_ID(r), L = SAGE_M_LEN(r);
-        const uint32_t x = L == 0u ? (nid | (m1 & 0xFFF00000u)) : (nid | (L << 20));      // a shorter match cannot end the line
-        M[p] = make_uint2(x, parent_new[nid]);
+    bool bad = false;
+    const uint64_t n4 = n_pos / 4u;
+    uint4* M4 = reinterpret_cast<uint4*>(M);
+    for (uint64_t q = (uint64_t)blockIdx.x * 256u + threadIdx.x; q < n4; q += (uint64_t)gridDim.x * 256u) {
+        const uint4 a = M4[2 * q], b = M4[2 * q + 1];             // (x, y) of positions 4q .. 4q+3
+        const uint32_t x0 = remap_one(a.x, remap, n_old, bad), x1 = remap_one(a.z, remap, n_old, bad);
+        const uint32_t x2 = remap_one(b.x, remap, n_old, bad), x3 = remap_one(b.z, remap, n_old, bad);
+        const uint32_t y0 = parent_new[SAGE_M_ID(x0)], y1 = parent_new[SAGE_M_ID(x1)];
+        const uint32_t y2 = parent_new[SAGE_M_ID(x2)], y3 = parent_new[SAGE_M_ID(x3)];
+        M4[2 * q] = make_uint4(x0, y0, x1, y1);
+        M4[2 * q + 1] = make_uint4(x2, y2, x3, y3);
     }
+    if (blockIdx.x == 0 && threadIdx.x < (uint32_t)(n_pos - 4u * n4)) {
+        const uint64_t p = 4u * n4 + threadIdx.x;
+        const uint32_t x = remap_one(M[p].x, remap, n_old, bad);
+        M[p] = make_uint2(x, parent_new[SAGE_M_ID(x)]);
+    }
+    if (bad) flags[FLAG_SET_OVERFLOW] = 1;
 }
 
 // NW = 8-byte key words compared, ML = longest length hashed and probed (max_len <= ML <= 8 * NW): the instantiation
@@ -703,32 +720,17 @@ __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ 
         // branch); lanes that do not take part are masked through their candidate bits, not through EXEC.
         if constexpr (QUEUED) {
             uint2* q = mq_all + (tid >> 6) * MQ_CAP;
-#ifndef SAGE_MATCH_CLASSES
-#define SAGE_MATCH_CLASSES 5
-#endif
-#if SAGE_MATCH_CLASSES == 5
-            if constexpr (ML >= 9) {
-                // (finer classes = more chances to stop early = fewer requests, up to a point: 13+, 9..12, 7..8, 5..6, 3..4
-                // measures 6.53 ms per 152 MB, 9+, 5..8, 3..4 6.77, one class per length 7.07)
+if constexpr (ML >= 9) {
+                // Five length classes, longest first.  A lane stops at its first hit, so finer classes mean fewer wasted
+                // probes and coarser ones fewer dependent rounds per tile; both cost.  Measured with the first-hit rule, ms per
+                // 152 MB: 2 classes (7+, 3..6) 7.21, 3 (9+, 5..8, 3..4) 6.02, 4 (11+, 7..10, 5..6, 3..4) 5.93, these 5 5.74,
+                // 7 (the short lengths one by one) 6.23, 9 6.77.
                 if constexpr (ML >= 13) { if (__any((cand >> 12) != 0u)) probe_queued<NW, 13, ML, ML>(v, cand, fh, W, top, q, lane); }
                 if (__any(((cand >> 8) & 0xFu) != 0u)) probe_queued<NW, 9, (ML < 12 ? ML : 12), ML>(v, cand, fh, W, top, q, lane);
             }
             probe_queued<NW, 7, 8, ML>(v, cand, fh, W, top, q, lane);
             probe_queued<NW, 5, 6, ML>(v, cand, fh, W, top, q, lane);
             probe_queued<NW, 3, 4, ML>(v, cand, fh, W, top, q, lane);
-#elif SAGE_MATCH_CLASSES == 3
-            if constexpr (ML >= 9) { if (__any((cand >> 8) != 0u)) probe_queued<NW, 9, ML, ML>(v, cand, fh, W, top, q, lane); }
-            probe_queued<NW, 5, (ML < 8 ? ML : 8), ML>(v, cand, fh, W, top, q, lane);
-            probe_queued<NW, 3, 4, ML>(v, cand, fh, W, top, q, lane);
-#elif SAGE_MATCH_CLASSES == 4
-            if constexpr (ML >= 11) { if (__any((cand >> 10) != 0u)) probe_queued<NW, 11, ML, ML>(v, cand, fh, W, top, q, lane); }
-            if constexpr (ML >= 7) probe_queued<NW, 7, (ML < 10 ? ML : 10), ML>(v, cand, fh, W, top, q, lane);
-            probe_queued<NW, 5, 6, ML>(v, cand, fh, W, top, q, lane);
-            probe_queued<NW, 3, 4, ML>(v, cand, fh, W, top, q, lane);
-#else
-            if constexpr (ML >= 7) { if (__any((cand >> 6) != 0u)) probe_queued<NW, 7, ML, ML>(v, cand, fh, W, top, q, lane); }
-            probe_queued<NW, 3, (ML < 6 ? ML : 6), ML>(v, cand, fh, W, top, q, lane);
-#endif
         } else {
             if constexpr (ML >= 9) probe_sparse<NW, 9, ML, ML>(v, cand, fh, W, top);
             const uint32_t c1 = top.m2 == 0u ? cand : 0u;

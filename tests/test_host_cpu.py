@@ -248,3 +248,25 @@ def test_bench_shards_share_one_lexicon():
     assert len(wa & wc) > 0.6 * min(len(wa), len(wc))          # same word types
     d, _ = synth.make_corpus(3000, seed=8, n_types=4000)
     assert len(wa & words(d)) < 0.2 * len(wa)                  # another seed is another language
+
+
+def test_tokenizer_remembers_a_pure_prune():
+    """set_vocabulary notes when the new vocabulary only lost keys (SaGeVocabBuilder.py:159-192) and keeps the id map the
+    engine needs to move its resident matches (sage_set_vocab_pruned); anything else is a full rebuild."""
+    from sage_amd import SaGeTokenizer
+    base = [bytes([b]) for b in range(256)]
+    vocab = base + [b"ab", b"abc", b"abcd", b"xy", b"xyz"]
+    m = SaGeTokenizer(vocab, 8)
+    assert m.prune_map is None and m.vocab_version == 1
+    m.set_vocabulary(base + [b"ab", b"abcd", b"xyz"])          # pruned: abc, xy -- ids re-compacted
+    version, o2n = m.prune_map
+    assert version == 1 and len(o2n) == len(vocab)
+    assert o2n[:256].tolist() == list(range(256))
+    assert o2n[256:].tolist() == [256, -1, 257, -1, 258]
+    m.set_vocabulary(base + [b"ab", b"abcd", b"xyz", b"new"])  # gained a key: not a prune
+    assert m.prune_map is None
+    m.set_vocabulary(base + [b"abcd", b"ab"])                  # lost one and REORDERED the rest: still only lost keys
+    version, o2n = m.prune_map
+    assert version == 3 and o2n[256:].tolist() == [257, 256, -1, -1]
+    with pytest.raises(Exception, match="missing byte"):
+        m.set_vocabulary(base[1:] + [b"ab"])
