@@ -368,19 +368,19 @@ void launch_pairs(sage_ctx* c, const T* emb, const uint32_t* tok_w0, uint32_t n_
                                                                     c->gcache.as<double2>(), c->flags.as<uint32_t>(), nullptr);
 }
 
-template <int G, int EPL, typename T>
+template <int G, int EPL, typename T, int NS = 5>
 void launch_dots(sage_ctx* c, const T* emb, uint32_t n_occ, const uint32_t* list, const uint32_t* list_count, int cls) {
     Prof p(c, cls);
     // persistent: exactly as many workgroups as the chip holds at once (a partial second round would double the time)
     static std::atomic<int> cached{0};   // per instantiation; the same for every gfx950 device
     int per_cu = cached.load(std::memory_order_relaxed);
     if (per_cu == 0) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_dots<G, EPL, T, 5>, 256, 0) != hipSuccess || per_cu < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_dots<G, EPL, T, NS>, 256, 0) != hipSuccess || per_cu < 1)
             per_cu = 4;
         cached.store(per_cu, std::memory_order_relaxed);
     }
     const uint32_t grid = std::min<uint32_t>(cdiv(n_occ, 256 / G), (uint32_t)c->n_cu * (uint32_t)std::max(per_cu, 1));
-    k_dots<G, EPL, T, 5><<<grid, 256, 0, c->stream>>>(
+    k_dots<G, EPL, T, NS><<<grid, 256, 0, c->stream>>>(
         c->desc.as<uint4>(), c->pool.as<uint32_t>(), n_occ, c->dot_off.as<uint32_t>(), emb, (uint32_t)c->emb_rows,
         (uint32_t)c->dp, c->dots.as<double>(), c->flags.as<uint32_t>(), list, list_count);
 }
