@@ -117,6 +117,51 @@ def test_a_rank_whose_step_fails_fails_every_rank(tmp_path):
     assert (tmp_path / "after0.txt").read_text() == want == (tmp_path / "after1.txt").read_text()
 
 
+def _rccl_rank_main(rank, world, port, out_dir):
+    sys.path.insert(0, str(REPO))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SAGE_DIST_SINGLE_RANK="1")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    from sage_amd import SaGeTokenizer
+    from sage_amd import dist as sdist
+    from sage_amd.parallel import PackedCorpus, get_engine, segment_line_bounds, sync_corpus_shard, sync_embeddings, sync_vocab
+    g, vocab, emb = _golden_inputs()
+    assert sdist.device_collectives(dist)                    # backend "nccl" = RCCL: CUDA tensors go straight into the collectives
+    model = SaGeTokenizer(vocab, int(g["max_len"]))
+    corpus = PackedCorpus(g["line_bytes"], g["line_off"])
+    eng = get_engine()
+    sync_vocab(eng, model); sync_embeddings(eng, emb)
+    local = sync_corpus_shard(eng, corpus, segment_line_bounds(len(corpus), WORKERS), rank, world)
+    buf = sdist.StepBuffers(model.id_space(), eng.hist_len)
+    sdist.step_into(eng, local, buf, dist)                   # the step, then combine() over RCCL on the device tensors
+    torch.cuda.synchronize()
+    got = sdist.broadcast_array(emb[:7] if rank == 0 else None, src=0)     # the embeddings broadcast, through RCCL too
+    assert np.array_equal(got, emb[:7])
+    sdist.assert_same_on_all_ranks((len(corpus), 5), "test tuple")
+    occ = buf.occ.cpu().numpy()
+    ids = np.nonzero(occ)[0]
+    np.savez(Path(out_dir) / "rccl.npz", tt=int(buf.tot[0]), ttr=int(buf.tot[1]), ids=ids, vals=buf.loss.cpu().numpy()[ids])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_collectives_on_device_tensors(tmp_path):
+    """The RCCL branch of the combine (`device_collectives`: backend "nccl", CUDA tensors handed to all_reduce /
+    all_gather_into_tensor / broadcast without host staging).  A one-GPU box cannot hold two RCCL ranks, so the group has
+    ONE rank: every collective of the product path still runs through RCCL on device memory, and the result must be the
+    reference's W=4 golden."""
+    import torch.multiprocessing as mp
+    g, _, _ = _golden_inputs()
+    mp.spawn(_rccl_rank_main, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    r = np.load(tmp_path / "rccl.npz")
+    assert int(r["tt"]) == int(g[f"w{WORKERS}_total_tokens"]) and int(r["ttr"]) == int(g[f"w{WORKERS}_total_triples"])
+    assert r["ids"].tolist() == g[f"w{WORKERS}_loss_ids"].tolist()
+    want = g[f"w{WORKERS}_loss_vals"]
+    np.testing.assert_allclose(r["vals"], want, rtol=1e-5, atol=1e-9 * max(1.0, float(np.abs(want).max())))
+
+
 def test_distributed_entry_point_without_a_process_group():
     """run_sage_distributed on one rank (no process group) is run_sage_parallel."""
     from sage_amd import SaGeTokenizer, synth
