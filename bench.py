@@ -76,30 +76,30 @@ def pmc_traffic(kernel_class, args):
     return None
 
 
-def roofline_object(dom, achieved, avg_ms, launches_per_step, per_kernel_bytes, eb, args, compulsory=None):
-    """The contract's roofline object for the kernel with the largest share of the step.  Besides the algorithmic rate it
-    carries the MEASURED L2-miss-side rate (PMC bytes of the committed pass over the live launch time): for the gather
-    and probe kernels that is the number to hold against the 8 TB/s peak, because their algorithmic bytes are partly
-    served by L2 (score) or are a small part of what the probes drag in (match)."""
+def roofline_object(dom, avg_ms, launches_per_step, per_kernel_bytes, named_bytes, eb, args):
+    """The contract's roofline object for the kernel with the largest share of the step: algorithmic bytes per launch over
+    the average launch time measured live (HIP events on the library's stream), against HBM's 8 TB/s.  Besides it the
+    MEASURED L2-miss-side rate (PMC bytes of this workload's committed pass over the same launch time)."""
     traffic = pmc_traffic(dom, args)
+    alg = per_kernel_bytes[dom] / launches_per_step
+    achieved = alg / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     out = {"bound": CLASS_BOUND.get(dom, "hbm"), "kernel": dom, "kernel_name": CLASS_KERNEL.get(dom, dom),
            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
            "avg_launch_ms": avg_ms, "launches_per_step": launches_per_step,
-           "algorithmic_bytes_per_launch": per_kernel_bytes[dom] / launches_per_step, "elem_bytes": eb,
-           "note": "peak is HBM's 8 TB/s for every kernel; `frac` uses algorithmic bytes, `traffic_frac` the measured "
-                   "L2-miss-side bytes (FETCH_SIZE x 2 + WRITE_SIZE) over the same launch time.  The score kernel hands "
-                   "its lanes ~6 TB/s of embedding rows, a third of them from L1/L2 (pad rows shared by consecutive "
-                   "occurrences), the rest through the fabric: bound by gather latency at 4 waves per SIMD; pairs and "
-                   "match pull 6-7 TB/s through the fabric (DESIGN.md, Kernels)"}
+           "algorithmic_bytes_per_launch": alg, "elem_bytes": eb,
+           "note": "peak is HBM's 8 TB/s for every kernel.  `frac` = algorithmic bytes / launch time / peak; for the gather "
+                   "kernels (score, fix) the algorithmic bytes count an embedding row ONCE per 32 consecutive occurrences "
+                   "(unique_rows_per_32_occurrences) plus 64 B of descriptor per occurrence, so cache hits on repeated rows "
+                   "cannot push it past 1.  `named_rows_GBs` is the rate at which rows reach the lanes when every window "
+                   "row is counted every time (a delivery rate, not a fraction of HBM: L1/L2 serve the repeats).  "
+                   "`traffic_frac` = measured L2-miss-side bytes (FETCH_SIZE x 2 + WRITE_SIZE) over the same time"}
     if traffic and avg_ms:
         out["traffic_GBs"] = traffic["fetch_x2"] / 1e9 / (avg_ms * 1e-3)
         out["traffic_frac"] = out["traffic_GBs"] / HBM_PEAK_GBS
-    if compulsory and dom in compulsory and avg_ms:
-        # a gather kernel's algorithmic bytes count a row every time a window names it; the compulsory bytes count it once
-        # per window of 32 consecutive occurrences (what the kernel keeps in flight): <= algorithmic by construction
-        cb = compulsory[dom] / launches_per_step
-        out["compulsory_bytes_per_launch"] = cb
-        out["frac_compulsory"] = cb / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    if dom in named_bytes and avg_ms:
+        out["compulsory_bytes_per_launch"], out["frac_compulsory"] = alg, out["frac"]     # (the same figure under round 2's names)
+        out["named_rows_bytes_per_launch"] = named_bytes[dom] / launches_per_step
+        out["named_rows_GBs"] = named_bytes[dom] / launches_per_step / (avg_ms * 1e-3) / 1e9
     return out
 
 
@@ -149,11 +149,13 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-def algorithmic_bytes(st, dim):
+def algorithmic_bytes(st, dim, uniq=None):
     """Per step and rank, per kernel class: the bytes the algorithm has to move (Kernels, states each).
     e = bytes per stored embedding element on the main pass (4: the lossless float32 copy).  With float32 row storage the
     occurrences are split: the score kernel runs on the EXACT list only (its window rows, its descriptors), the mixed
-    float64 kernel ("fix") on the rest, gathering marked rows from the float64 matrix and the others from the copy."""
+    float64 kernel ("fix") on the rest, gathering marked rows from the float64 matrix and the others from the copy.
+    For the two gather kernels the figure returned here counts every row EVERY time a window names it ("named rows");
+    `compulsory_bytes` counts a row once per 32 consecutive occurrences and is what their roofline fractions use."""
     e = st["emb_elem_bytes"]
     tok, occ, nb = st["tokens"], st["occurrences"], st["corpus_bytes"]
     occ_fix, rows_fix, rows_f64 = st["f64_fix_occurrences"], st["window_rows_inexact"], st["f64_rows_gathered"]
@@ -173,8 +175,11 @@ def algorithmic_bytes(st, dim):
 
 
 def compulsory_bytes(st, uniq, dim):
-    """The gather kernels' bytes when a row is counted ONCE per window of 32 consecutive occurrences
-    (sage_measure_unique_rows over the last batch, scaled to the step by occurrences)."""
+    """The gather kernels' ALGORITHMIC bytes: a row counted ONCE per window of 32 consecutive occurrences -- neighbouring
+    occurrences share their pad rows, so a kernel that holds 32 occurrences in flight (k_dots hands them out that way)
+    need not move a row twice -- plus the descriptors (sage_measure_unique_rows over the last batch, scaled to the step
+    by occurrences).  Never more than the named-row figure, so a fraction built on it cannot pass 1 through cache hits on
+    repeated rows, which the named-row figure does at D = 300."""
     if not uniq or uniq["occurrences"] <= 0:
         return None
     scale = st["occurrences"] / uniq["occurrences"]
@@ -338,28 +343,45 @@ def main():
         ranked = sorted((v, k) for k, v in scored.items())
         doomed = {model.id_to_bytes(t) for _, t in ranked[:len(scored) - target]}
         survivors = [k for k in vocab if k not in doomed]
+        keep_old_ids = np.array([i for i, k in enumerate(vocab) if k not in doomed], dtype=np.int64)
+        # Two matrices, as a schedule meets them: STALE = the matrix of the unpruned vocabulary read with the re-compacted
+        # ids, which is what the reference does between two retrain labels (SaGeVocabBuilder.py:89-91,192: ids move,
+        # rows do not) -- other ids now meet the float64 uniform rows, most windows touch one and the float32 copy stops
+        # paying; FRESH = rows in the order of the new ids, what a step right after a retrain label sees.
         res = {}
-        for mode, incr in (("carried_matches", "1"), ("rematched", "0")):
-            model.set_vocabulary(vocab)
-            parallel.sync_vocab(eng, model)
-            eng.invalidate_matches()
-            step_into(eng, bounds, buf, None)             # the step before the prune (leaves a complete match table)
-            os.environ["SAGE_INCREMENTAL_MATCH"] = incr
-            model.set_vocabulary(survivors)
-            torch.cuda.synchronize()
-            ta = time.perf_counter()
-            parallel.sync_vocab(eng, model)
-            tb = time.perf_counter()
-            step_into(eng, bounds, buf, None)
-            torch.cuda.synchronize()
-            tc = time.perf_counter()
-            res[mode] = {"vocabulary_ms": (tb - ta) * 1e3, "step_ms": (tc - tb) * 1e3, "total_ms": (tc - ta) * 1e3,
-                         "no_matcher": eng.step_stats()["no_matcher"], "total_tokens": int(buf.tot[0].item()),
-                         "total_triples": int(buf.tot[1].item())}
+        for matrix, E in (("stale_matrix", emb), ("fresh_matrix", np.ascontiguousarray(emb[keep_old_ids]))):
+            res[matrix] = {}
+            for mode, incr in (("carried_matches", "1"), ("rematched", "0")):
+                model.set_vocabulary(vocab)
+                parallel.sync_vocab(eng, model)
+                eng.set_embeddings(emb)                       # (also resets the step's float32 / float64 storage choice)
+                eng.invalidate_matches()
+                step_into(eng, bounds, buf, None)             # the step before the prune (leaves a complete match table)
+                os.environ["SAGE_INCREMENTAL_MATCH"] = incr
+                model.set_vocabulary(survivors)
+                eng.set_embeddings(E)
+                torch.cuda.synchronize()
+                ta = time.perf_counter()
+                parallel.sync_vocab(eng, model)
+                tb = time.perf_counter()
+                eng.set_profiling(True)
+                eng.reset_kernel_times()
+                step_into(eng, bounds, buf, None)
+                torch.cuda.synchronize()
+                tc = time.perf_counter()
+                eng.set_profiling(False)
+                st2 = eng.step_stats()
+                res[matrix][mode] = {
+                    "vocabulary_ms": (tb - ta) * 1e3, "step_ms": (tc - tb) * 1e3, "total_ms": (tc - ta) * 1e3,
+                    "no_matcher": st2["no_matcher"], "total_tokens": int(buf.tot[0].item()),
+                    "total_triples": int(buf.tot[1].item()), "occurrences": st2["occurrences"],
+                    "f64_fix_occurrences": st2["f64_fix_occurrences"], "emb_elem_bytes": st2["emb_elem_bytes"],
+                    "kernel_ms": {k: round(v[0], 3) for k, v in eng.kernel_times().items() if v[0] > 0}}
+            a, b = res[matrix]["carried_matches"], res[matrix]["rematched"]
+            assert a["no_matcher"] == 1 and b["no_matcher"] == 0
+            assert (a["total_tokens"], a["total_triples"]) == (b["total_tokens"], b["total_triples"])
         os.environ.pop("SAGE_INCREMENTAL_MATCH", None)
-        assert res["carried_matches"]["no_matcher"] == 1 and res["rematched"]["no_matcher"] == 0
-        assert (res["carried_matches"]["total_tokens"], res["carried_matches"]["total_triples"]) == \
-               (res["rematched"]["total_tokens"], res["rematched"]["total_triples"])
+        eng.set_embeddings(emb)
         after_prune = {"active_before": len(scored), "target": target, "pruned_keys": len(vocab) - len(survivors),
                        "vocabulary_after": len(survivors), **res}
         model.set_vocabulary(vocab)
@@ -377,13 +399,16 @@ def main():
 
         def A_of(e):
             return b_bar + 9 + f_m * (r_bar * args.dim * e + 16 * p_bar)
-        per_kernel_bytes = algorithmic_bytes(st, args.dim)
+        named_all = algorithmic_bytes(st, args.dim)
+        comp = compulsory_bytes(st, uniq, args.dim) or {}
+        per_kernel_bytes = {**named_all, **comp}          # gather kernels: rows once per 32 occurrences (see compulsory_bytes)
+        named_bytes = {k: named_all[k] for k in comp}
         dom = max(per_kernel_bytes, key=lambda k: kt[k][0])
         dom_ms, dom_n = kt[dom]
         launches_per_step = max(1, dom_n // args.steps)
         avg_ms = dom_ms / max(1, dom_n)
-        achieved = per_kernel_bytes[dom] / launches_per_step / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         step_s = dt / args.steps
+        step_alg_bytes = sum(per_kernel_bytes.values())   # this rank's shard
 
         def step_gbs(e):
             return A_of(e) * total_tokens / step_s / 1e9 / world
@@ -397,7 +422,7 @@ def main():
             "ms_per_step": ms_per_step,
             "run_sage_parallel_ms": api_ms,
             "run_sage_parallel_parts": api_parts,
-            "step_after_prune_ms": after_prune["carried_matches"]["total_ms"] if after_prune else None,
+            "step_after_prune_ms": after_prune["stale_matrix"]["carried_matches"]["total_ms"] if after_prune else None,
             "step_after_prune": after_prune,
             "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
@@ -414,12 +439,17 @@ def main():
                        "lines_per_gpu": int(eng.n_lines), "workload_tag": workload_tag(args), "vocab": len(vocab), "dim": args.dim, "max_len": args.max_len,
                        "corpus_bytes_per_gpu": int(st["corpus_bytes"]), "total_tokens": total_tokens,
                        "total_triples": total_triples},
-            "roofline": roofline_object(dom, achieved, avg_ms, launches_per_step, per_kernel_bytes, eb, args,
-                                        compulsory_bytes(st, uniq, args.dim)),
+            "roofline": roofline_object(dom, avg_ms, launches_per_step, per_kernel_bytes, named_bytes, eb, args),
             "unique_rows_per_32_occurrences": uniq,
             "step_roofline": {"measured_hbm_bytes_per_step": pmc_traffic("__step_total__", args) if world == 1 else None,
-                              "bytes_per_token_A": A_of(eb), "achieved_GBs_per_gpu": step_gbs(eb), "frac": step_gbs(eb) / HBM_PEAK_GBS,
-                              "bytes_per_token_A_e8": A_of(8), "frac_e8": step_gbs(8) / HBM_PEAK_GBS,
+                              # the step's algorithmic bytes = the sum of its kernels' (kernel_roofline), per token of the shard
+                              "bytes_per_token_A": step_alg_bytes / tokens_local,
+                              "achieved_GBs_per_gpu": step_alg_bytes / step_s / 1e9,
+                              "frac": step_alg_bytes / step_s / 1e9 / HBM_PEAK_GBS,
+                              # SURVEY.md 8d's formula A = b + 9 + f_m (r D e + 16 p) names every row of every window and
+                              # base span at D*e bytes: delivery rates (GB/s), not fractions -- at D = 300 they pass HBM's peak
+                              "survey_model": {"bytes_per_token_e4": A_of(4), "bytes_per_token_e8": A_of(8),
+                                               "GBs_e4": step_gbs(4), "GBs_e8": step_gbs(8)},
                               "b_bar": b_bar, "f_m": f_m, "r_bar": r_bar, "p_bar": p_bar, "emb_elem_bytes": eb,
                               "window_rows_per_occurrence": st["window_rows"] / occ,
                               "window_pairs_per_occurrence": st["window_pairs"] / occ,
@@ -434,8 +464,7 @@ def main():
                                     "GBps": per_kernel_bytes[k] / (kt[k][0] / args.steps * 1e-3) / 1e9 if kt[k][0] > 0 else 0.0,
                                     "frac": per_kernel_bytes[k] / (kt[k][0] / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS if kt[k][0] > 0 else 0.0}
                                 for k in per_kernel_bytes},
-            "kernel_frac_compulsory": {k: v / (kt[k][0] / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBS
-                                       for k, v in (compulsory_bytes(st, uniq, args.dim) or {}).items() if kt[k][0] > 0},
+            "kernel_named_rows_GBps": {k: v / (kt[k][0] / args.steps * 1e-3) / 1e9 for k, v in named_bytes.items() if kt[k][0] > 0},
             # the same kernels by MEASURED L2-miss-side bytes (committed PMC pass) over the live kernel time
             "kernel_traffic_GBps": {k: (lambda t: t["fetch_x2"] * (kt[k][1] / args.steps) / (kt[k][0] / args.steps * 1e-3) / 1e9
                                         if t and kt[k][0] > 0 else None)(pmc_traffic(k, args)) for k in per_kernel_bytes if k not in ("walk", "fix")},

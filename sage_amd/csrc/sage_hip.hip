@@ -909,8 +909,8 @@ extern "C" int sage_debug_match_stats(unsigned long long* out, int reset) {
 #endif
 #ifdef PHASE_CLOCKS
 extern "C" int sage_debug_phase_clocks(unsigned long long* out, int reset) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_dbg), 32 * 8) != hipSuccess) return 1;
-    if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_dbg), z, 32 * 8) != hipSuccess) return 1; }
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_dbg), 48 * 8) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[48] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_dbg), z, 48 * 8) != hipSuccess) return 1; }
     return 0;
 }
 #endif

@@ -679,7 +679,7 @@ __device__ __forceinline__ void dots_body(const uint4* __restrict__ desc, const 
     __syncthreads();
     constexpr uint32_t DOTS_WIN = 256u / G < 32u ? 32u : 256u / G;
     const uint32_t fend = n;
-    uint32_t fi = 0, foi = 0, fj = 0, fL = 0, fpl = 0, fk = 0;
+    uint32_t fi = 0, fj = 0, fL = 0, fpl = 0, fk = 0;
     auto next_index = [&]() {
         uint32_t tk = 0;
         if (gl == 0u) tk = atomicAdd(&next_occ, 1u);
@@ -689,18 +689,49 @@ __device__ __forceinline__ void dots_body(const uint4* __restrict__ desc, const 
     };
     next_index();
     const uint32_t* fids = nullptr;
-    uint4 nh = make_uint4(0, 0, 0, 0);
-    if (fi < fend) { foi = list ? list[fi] : fi; nh = desc[(size_t)foi * 4]; }
+    // The NEXT occurrence's words -- list entry, descriptor head, dot offset -- are a chain of two dependent loads.  They
+    // are fetched by a two-stage pipeline that runs ONCE PER STEP, unconditionally and outside every branch: stage 1 loads
+    // the list entry of position fi, stage 2 (a step later) the descriptor head and dot offset of that entry.  Between two
+    // openings fi does not change, so the steps re-read the same cached words; what this buys is that the opening branch
+    // contains no load at all.  (With the loads inside that branch the compiler had to wait for ALL outstanding vector
+    // memory -- `s_waitcnt vmcnt(0)`, row gathers included -- twice per opening plus once per loop trip, because a value
+    // loaded on one side of a divergent branch is copied at the join: 1.6 full drains per step of a wave.)
+    uint32_t a_foi = 0;                                  // stage 1: list entry of position fi (in flight for one step)
+    uint32_t b_foi = 0, b_hx = 0, b_out = 0;             // stage 2: entry, descriptor word 0 and dot offset
+    uint32_t age = 0;                                    // pipeline steps since fi last changed; >= 2: stage 2 belongs to fi
+    const uint32_t* desc_w = reinterpret_cast<const uint32_t*>(desc);
+    auto prefetch_next = [&]() {
+        b_foi = a_foi < n_occ ? a_foi : 0u;              // (stage 1 of a position past the end read entry 0)
+        b_hx = desc_w[(size_t)b_foi * 16];
+        b_out = dot_off[b_foi];
+        const uint32_t p = fi < fend ? fi : 0u;
+        a_foi = list ? list[p] : p;
+        age += age < 2u ? 1u : 0u;
+    };
     auto fetch_id = [&](uint32_t& id, uint32_t& meta, uint32_t& out) {
         meta = 0; id = 0;
-        if (fj == fL) {   // open the next occurrence from the prefetched header, prefetch the one after
+        if (fj == fL) {   // open the next occurrence from the prefetched words
             if (fi >= fend) return;
-            const Win w = win_decode(nh.x, nh.z, nh.w);
+            uint32_t o = b_foi, hx = b_hx, ov = b_out;
+            if (age < 2u) {       // not there yet: a group's first occurrence (the pipeline needs two steps)
+                o = list ? list[fi] : fi;
+                hx = desc_w[(size_t)o * 16];
+                ov = dot_off[o];
+                // consumed here, inside the branch, so that the wait for these loads stays inside it
+                asm volatile("" : "+v"(hx), "+v"(ov));
+            }
+            uint32_t hy = 0, hz = 0;
+            if (hx & SAGE_DH_OVER) {   // a pooled window (1.5 % of the occurrences): its pool offset and length, loaded here
+                hy = desc_w[(size_t)o * 16 + 1];
+                hz = desc_w[(size_t)o * 16 + 2];
+                asm volatile("" : "+v"(hy), "+v"(hz));
+            }
+            const Win w = win_decode(hx, hz, 0u);
             fL = w.L; fpl = w.pl; fk = w.k; fj = 0;
-            fids = w.pooled ? pool + nh.y : reinterpret_cast<const uint32_t*>(desc + (size_t)foi * 4) + 1;
-            out = dot_off[foi];
+            fids = w.pooled ? pool + hy : desc_w + (size_t)o * 16 + 1;
+            out = ov;
             next_index();
-            if (fi < fend) { foi = list ? list[fi] : fi; nh = desc[(size_t)foi * 4]; }
+            age = 0;
         }
         id = fids[fj];
         // element fj is in the centre [pl, pl+k) iff (fj - pl) < k unsigned; the same for its two predecessors
@@ -713,8 +744,9 @@ __device__ __forceinline__ void dots_body(const uint4* __restrict__ desc, const 
     // (or per occurrence tail) instead of one 8-byte store per dot
     uint32_t wr = 0, pend = 0;   // write cursor into dots[] (first pending dot), pending dots
     double mydot = 0.0;
+    if (n == 0u) return;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) fetch_id(qid[i], qm[NF + i], qo[NF + i]);
+    for (int i = 0; i < NI; ++i) { fetch_id(qid[i], qm[NF + i], qo[NF + i]); prefetch_next(); }
     uint32_t bw = 0;       // MIXED: bitmap word of the id whose row load is issued next
     if constexpr (MIXED) bw = bitmap[(qid[0] < emb_rows ? qid[0] : 0u) >> 5];
     for (;;) {
@@ -734,6 +766,7 @@ __device__ __forceinline__ void dots_body(const uint4* __restrict__ desc, const 
 #pragma unroll
             for (int i = 0; i + 1 < NI; ++i) qid[i] = qid[i + 1];
             fetch_id(qid[NI - 1], qm[NQ - 1], qo[NQ - 1]);
+            prefetch_next();
             if (rid >= emb_rows) { if (rlive) flags[FLAG_ROW_OOB] = 1; rid = 0; }
             if constexpr (MIXED) {
                 const bool from32 = ((bw >> (rid & 31u)) & 1u) == 0u;
@@ -870,15 +903,17 @@ __global__ __launch_bounds__(256) void k_unique_rows(const uint4* __restrict__ d
 // entries holds its wave for 100 dependent reads: phase clocks put 35 % of the kernel there.  The tile's occurrences
 // are consecutive tokens, so the pair-cache entries of tokens t0-2 .. t0+509 (t0 = the tile's first token) are
 // loaded a tile ahead, two per thread, turned into prefix sums in LDS, and a range becomes two reads.  The prefix
-// sums of a tile stay below 512 * LOGSIG_PS_LIMIT, so a difference is off by < 1e-9 absolute; a tile that holds a
-// larger or non-finite entry, a span that leaves the staged range, and deterministic mode (which adds fixed-point
+// sums of a tile (1,024 entries, each below LOGSIG_PS_LIMIT = 64 in magnitude, i.e. dots above -64) stay below 2^16,
+// so a range read as a difference of two of them is off by a few ulp(2^16) = 1.5e-11: < 2e-10 ABSOLUTE per occurrence in
+// the worst case, ~1e-12 on word2vec-sized dots (an absolute bound, not a relative one: DESIGN.md, Oracle and parity);
+// a tile that holds a larger or non-finite entry, a span that leaves the staged range, and deterministic mode (which adds fixed-point
 // terms, not float64 sums) add the entries one by one instead.
 // ----------------------------------------------------------------------------------------------------------
 #define LOGSIG_TILE 256
 #define LOGSIG_PF 8      // dots of a thread's slice loaded ahead (a tile of 256 occurrences has ~8 dots per thread)
 #define LOGSIG_WIN 6     // DET: pair-cache entries t-2 .. t+3 loaded ahead (centres of up to 4 base tokens)
 #define LOGSIG_GS 512    // pair-cache entries of a tile staged as prefix sums
-#define LOGSIG_PS_LIMIT 1.0e4
+#define LOGSIG_PS_LIMIT 64.0
 template <bool DET>
 __global__ __launch_bounds__(256) void k_logsig(const uint4* __restrict__ desc, const uint32_t* __restrict__ occ_tok,
                                                 const uint32_t* __restrict__ occ_a, uint32_t n_occ,

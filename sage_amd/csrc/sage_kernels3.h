@@ -269,7 +269,9 @@ __global__ __launch_bounds__(PART_THREADS) void k_key_partition3(const uint4* __
     uint32_t* misc = longs + PART_LONGS;                                      // [8]: tile scalars, wave sums
     const uint32_t tid = threadIdx.x;
     const uint32_t n_tiles = min(P.seg_tile_off[P.n_seg], max_tiles);
+    PH_DECL;
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        PH_START();
         if (tid == 0) misc[3] = 0u;     // long occurrences listed
         for (uint32_t i = tid; i < PART_NBK_MAX; i += PART_THREADS) cnt[i] = 0u;
         __syncthreads();
@@ -283,8 +285,10 @@ __global__ __launch_bounds__(PART_THREADS) void k_key_partition3(const uint4* __
         const bool one_round = o_hi - o_lo <= PART_THREADS;
         InlineOcc X;
         bool have = false;
+        PH_MARK(0);
         for (uint32_t o = o_lo + tid; o < o_hi; o += PART_THREADS) {
             load_inline(desc, occ_tok, tok_w0, o, X);
+            PH_MARK(1);
             if (X.d[0] & SAGE_DH_GIANT) continue;                             // k_key_giant's
             if (X.d[0] & SAGE_DH_OVER) {
                 // listed for the wave-per-occurrence loops.  A pooled occurrence has >= 27 position pairs, so a tile can hold
@@ -301,7 +305,9 @@ __global__ __launch_bounds__(PART_THREADS) void k_key_partition3(const uint4* __
                 atomicAdd(&cnt[sage_key_hash_a(make_key(a, lo, hi)) & mask], 1u);
             });
         }
+        PH_MARK(2);
         __syncthreads();
+        PH_MARK(3);
         // pooled occurrences (~1.5 % of them): a wave each, so that their dependent loads (header -> pool ids) overlap
         const uint32_t n_long = misc[3];
         // every pooled occurrence of the tile, a wave each: from the list, or -- when the list ran full -- from a scan of
@@ -324,6 +330,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_key_partition3(const uint4* __
             });
         });
         __syncthreads();
+        PH_MARK(4);
         // ---- exclusive scan of the bucket counts (2 per thread), bucket ranges reserved with coalesced atomics
         {
             const uint32_t c0 = cnt[2 * tid], c1 = cnt[2 * tid + 1];
@@ -372,6 +379,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_key_partition3(const uint4* __
         }
         if (MODE == 0) { __syncthreads(); continue; }
         __syncthreads();
+        PH_MARK(5);
         // ---- phase B: the same keys again, each into its place in the stage
         auto place = [&](const InlineOcc& x) {
             const uint32_t a = x.a;
@@ -391,6 +399,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_key_partition3(const uint4* __
                 place(X);
             }
         }
+        PH_MARK(6);
         for_pooled([&](uint32_t o) {
             const uint32_t t = occ_tok[o];
             const uint32_t a = SAGE_T_ID(tok_w0[t]);
@@ -402,6 +411,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_key_partition3(const uint4* __
             });
         });
         __syncthreads();
+        PH_MARK(7);
         // ---- copy-out: consecutive lanes write one bucket's run.  dst = rec + delta[b] + e with delta[b] = the bucket's
         // reserved start minus its start in the stage, kept as 64-bit words over the space of cnt and gbase
         {
@@ -426,7 +436,12 @@ __global__ __launch_bounds__(PART_THREADS) void k_key_partition3(const uint4* __
             if (dlt != ~0ull) rec[dlt + e] = key;
         }
         __syncthreads();
+        PH_MARK(8);
+#ifdef PHASE_CLOCKS
+        ph_d[9] += 1;
+#endif
     }
+    if (MODE == 1) PH_FLUSH(32, 10);
 }
 
 // Giant occurrences: one workgroup each, one global atomic per key.

@@ -63,8 +63,13 @@ def _build(root: Path, g, deterministic: bool):
     b = sage_amd.SaGeVocabBuilder(list(g["schedule"]), list(g["embeddings_schedule"]), max_len=g["max_len"],
                                   workers_number=g["workers"], random_seed=g["random_seed"])
     b.deterministic = deterministic
+    import time
+    t0 = time.time()
     try:
         b.build_vocab("c3", str(root / "corpus.txt"), str(root / "initial.vocab"), str(root / "partial.txt"), g["n_lines"] // 1000)
+        # (the reference took 1,933 s for this schedule with 4 worker processes on the 8 cores of the build container,
+        # tests/golden/make_readme_schedule.py; both sides include the stand-in word2vec's six passes over the corpus file)
+        print(f"build_vocab of the README schedule: {time.time() - t0:.1f} s (deterministic={deterministic})", flush=True)
     finally:
         os.environ.pop("SAGE_W2V_BACKEND", None)
         fake_gensim.uninstall()

@@ -28,7 +28,8 @@ def show(name, base, labels, ntile_idx):
     print(name, "tiles (thread 0's)", tiles, "clocks per tile", round(tot / max(tiles, 1)))
     for l, x in zip(labels, v):
         print(f"   {l:34s} {x / max(tiles, 1):9.0f}  {100.0 * x / max(tot, 1):5.1f} %")
-show("k_key_partition3<1>", 32, ["clear + tile set-up", "phase A (inline occurrences)", "barrier", "pooled A + barrier", "scan + reservations", "phase B (inline)", "pooled B + barrier", "copy-out"], 8)
+show("k_key_partition3<1>", 32, ["clear + tile table", "load_inline (first round)", "phase A keys + count atomics", "barrier", "pooled A + barrier", "scan + reservations + barrier",
+                                 "phase B (inline)", "pooled B + barrier", "copy-out + barrier"], 9)
 show("k_describe<false>", 0, ["loads + span + barrier", "segment search", "walk", "bitmap", "outputs + atomics", "list ballots + barriers + atomic",
                               "list stores + seg atomics + barrier", "descriptor write-out + barrier"], 8)
 show("k_logsig<false>", 16, ["tile set-up + 2 barriers", "loads (G window, dots)", "base sum", "owner search", "dot loop", "barrier", "accumulate"], 7)
