@@ -281,6 +281,16 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t* __restrict__ bitmap = D.inexact;
     PH_DECL;
+    // the first level of a tile's loads (its occurrences' token and position, the start of its span) is fetched a tile
+    // ahead, so a tile starts at its second level: the span of M and the occurrences' own words
+    uint32_t nx_t = 0, nx_p0 = 0, nx_P0 = 0;
+    auto first_level = [&](uint32_t b) {
+        const uint32_t it = b + threadIdx.x;
+        nx_t = it < n_items ? occ_tok[it] : 0u;
+        nx_p0 = it < n_items ? A.occ_pos[it] : 0u;
+        nx_P0 = b < n_items ? A.occ_pos[b] : 0u;
+    };
+    if (!LONG) first_level(blockIdx.x * 256u);
     for (uint32_t base = blockIdx.x * 256u; base < n_round; base += gridDim.x * 256u) {
         PH_START();
         const uint32_t item = base + threadIdx.x;
@@ -291,12 +301,20 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
         if (!LONG) {
             // 256 consecutive occurrences cover ~1.5 KB of text; their walks stay within a few hundred bytes of it.
             // Every dependent step of a walk is then an LDS read instead of an L2 round trip.
-            // the occurrence's own loads (two dependent levels) are issued with the span's, not after the barrier
-            t_pre = live ? occ_tok[o] : 0u;
-            p0_pre = live ? A.occ_pos[o] : 0u;
-            P0 = A.occ_pos[base];
-            for (uint32_t i = threadIdx.x; i < DESC_SPAN; i += 256u) span[i] = (P0 + i) < A.n_pos ? A.M[P0 + i].x : 0u;
+            // the occurrence's own loads are issued with the span's, not after the barrier
+            t_pre = nx_t;
+            p0_pre = nx_p0;
+            P0 = nx_P0;
+            uint32_t sp[DESC_SPAN / 256u];
+#pragma unroll
+            for (uint32_t q = 0; q < DESC_SPAN / 256u; ++q) {
+                const uint32_t i = threadIdx.x + 256u * q;
+                sp[q] = (P0 + i) < A.n_pos ? A.M[P0 + i].x : 0u;
+            }
             if (live) ow = load_occ_words(A, t_pre, p0_pre);
+            first_level(base + gridDim.x * 256u);
+#pragma unroll
+            for (uint32_t q = 0; q < DESC_SPAN / 256u; ++q) span[threadIdx.x + 256u * q] = sp[q];
             __syncthreads();
         }
         if (!LONG) PH_MARK(0);
@@ -682,8 +700,23 @@ __device__ __forceinline__ void dots_body(const uint4* __restrict__ desc, const 
     uint32_t fi = 0, fj = 0, fL = 0, fpl = 0, fk = 0;
     auto next_index = [&]() {
         uint32_t tk = 0;
-        if (gl == 0u) tk = atomicAdd(&next_occ, 1u);
-        tk = __shfl(tk, (int)((threadIdx.x & 63u) & ~(uint32_t)(G - 1)), 64);       // (the group's lanes branch together)
+        if constexpr (MIXED) {
+            // One LDS atomic per wave for all its groups that open an occurrence in this step, and no shuffle: every lane of
+            // an opening group (the group's lanes branch together) counts the LAST lanes of the opening groups below its
+            // own, so the lanes of a group derive the same ticket.  The shuffle of the other branch needs a lane-address
+            // register that lives through the whole loop; this kernel, held to 128 registers, spilled it and paid a scratch
+            // reload -- a full `vmcnt(0)` drain -- at every opening.  (In the float32 kernel, which has the register, the
+            // shuffle form is the faster one: 18.9 against 19.3 ms.)
+            const unsigned long long m = __ballot(gl == (uint32_t)(G - 1));
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            uint32_t base = 0;
+            if (rank == 0u && gl == (uint32_t)(G - 1)) base = atomicAdd(&next_occ, (uint32_t)__popcll(m));
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(m));
+            tk = base + rank;
+        } else {
+            if (gl == 0u) tk = atomicAdd(&next_occ, 1u);
+            tk = __shfl(tk, (int)((threadIdx.x & 63u) & ~(uint32_t)(G - 1)), 64);       // (the group's lanes branch together)
+        }
         const unsigned long long at = ((unsigned long long)(tk / DOTS_WIN) * gridDim.x + blockIdx.x) * DOTS_WIN + tk % DOTS_WIN;
         fi = at < (unsigned long long)n ? (uint32_t)at : n;
     };
@@ -700,7 +733,12 @@ __device__ __forceinline__ void dots_body(const uint4* __restrict__ desc, const 
     uint32_t b_foi = 0, b_hx = 0, b_out = 0;             // stage 2: entry, descriptor word 0 and dot offset
     uint32_t age = 0;                                    // pipeline steps since fi last changed; >= 2: stage 2 belongs to fi
     const uint32_t* desc_w = reinterpret_cast<const uint32_t*>(desc);
+    // (groups of 32 and 64 lanes -- rows of more than 512 bytes, D = 300 -- have 2 or 1 openings per wave to hide, not 8,
+    // and are bound by the bytes of their rows: there the three extra loads per step cost more than the drains, 23.1
+    // against 22.3 ms, so they keep the loads in the opening branch)
+    constexpr bool PIPE = G <= 16;
     auto prefetch_next = [&]() {
+        if constexpr (!PIPE) return;
         b_foi = a_foi < n_occ ? a_foi : 0u;              // (stage 1 of a position past the end read entry 0)
         b_hx = desc_w[(size_t)b_foi * 16];
         b_out = dot_off[b_foi];
@@ -713,7 +751,7 @@ __device__ __forceinline__ void dots_body(const uint4* __restrict__ desc, const 
         if (fj == fL) {   // open the next occurrence from the prefetched words
             if (fi >= fend) return;
             uint32_t o = b_foi, hx = b_hx, ov = b_out;
-            if (age < 2u) {       // not there yet: a group's first occurrence (the pipeline needs two steps)
+            if (!PIPE || age < 2u) {   // not there yet: a group's first occurrence (the pipeline needs two steps)
                 o = list ? list[fi] : fi;
                 hx = desc_w[(size_t)o * 16];
                 ov = dot_off[o];
