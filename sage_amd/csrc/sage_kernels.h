@@ -6,6 +6,15 @@
 #include <type_traits>
 #include "sage_common.h"
 
+// A workgroup barrier for kernels whose threads exchange data through LDS only.  __syncthreads() also orders GLOBAL memory:
+// its release fence makes every wave wait for all of its outstanding vector-memory operations (`s_waitcnt vmcnt(0)`), so a
+// prefetch issued before a barrier is waited for AT the barrier and overlaps nothing behind it.  Here only LDS traffic is
+// waited for; global loads stay in flight across the barrier (their results are per-thread registers, which no other
+// thread reads).  Not for code that passes data between threads through global memory.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 struct VocabDev {
     const uint4* buckets;     // nbuckets * 4 slots
     uint32_t bucket_mask;     // nbuckets - 1

@@ -733,12 +733,7 @@ __device__ __forceinline__ void dots_body(const uint4* __restrict__ desc, const 
     uint32_t b_foi = 0, b_hx = 0, b_out = 0;             // stage 2: entry, descriptor word 0 and dot offset
     uint32_t age = 0;                                    // pipeline steps since fi last changed; >= 2: stage 2 belongs to fi
     const uint32_t* desc_w = reinterpret_cast<const uint32_t*>(desc);
-    // (groups of 32 and 64 lanes -- rows of more than 512 bytes, D = 300 -- have 2 or 1 openings per wave to hide, not 8,
-    // and are bound by the bytes of their rows: there the three extra loads per step cost more than the drains, 23.1
-    // against 22.3 ms, so they keep the loads in the opening branch)
-    constexpr bool PIPE = G <= 16;
     auto prefetch_next = [&]() {
-        if constexpr (!PIPE) return;
         b_foi = a_foi < n_occ ? a_foi : 0u;              // (stage 1 of a position past the end read entry 0)
         b_hx = desc_w[(size_t)b_foi * 16];
         b_out = dot_off[b_foi];
@@ -751,7 +746,7 @@ __device__ __forceinline__ void dots_body(const uint4* __restrict__ desc, const 
         if (fj == fL) {   // open the next occurrence from the prefetched words
             if (fi >= fend) return;
             uint32_t o = b_foi, hx = b_hx, ov = b_out;
-            if (!PIPE || age < 2u) {   // not there yet: a group's first occurrence (the pipeline needs two steps)
+            if (age < 2u) {   // not there yet: a group's first occurrence (the pipeline needs two steps)
                 o = list ? list[fi] : fi;
                 hx = desc_w[(size_t)o * 16];
                 ov = dot_off[o];

@@ -497,9 +497,15 @@ __global__ __launch_bounds__(PART_THREADS) void k_key_dedupe3(const unsigned lon
     extern __shared__ unsigned long long set3[];
     unsigned long long n_distinct = 0, n_read = 0;
     const uint32_t tid = threadIdx.x;
-    // software pipeline over the workgroup's buckets: the records of bucket i+1 and the size and place of bucket i+2
-    // are loaded while bucket i is inserted, so no global latency is exposed between buckets
-    uint64_t nx[DD3_UNR];
+    // The workgroup's work is ONE stream of chunks of 8,192 records: (bucket, pass, chunk), a bucket of up to SET3_FILL
+    // records being one pass of one or two chunks, a larger one several passes over all of its chunks.  While a chunk is
+    // inserted the next chunk's records are on their way (and the sizes of the next two buckets), whatever it belongs to:
+    // one loop body, no tail loop.  Three things keep those loads in flight: they are UNCONDITIONAL (a thread without a
+    // record at that place reads record 0 of the array and ignores it) -- with a branch around each load the compiler
+    // cannot count how many are outstanding and waits for all of them, `vmcnt(0)`, before it touches the current chunk;
+    // the barriers are lds_barrier(), not __syncthreads(), whose fence waits for global loads too; and no rarely taken
+    // loop with loads of its own shares the body (its registers made the compiler drain at the loop head).
+    constexpr uint32_t CHUNK = PART_THREADS * DD3_UNR;
     auto meta = [&](uint32_t b, uint32_t& cnt, unsigned long long& off) {
         cnt = 0; off = 0;
         if (b >= n_buckets) return;
@@ -507,42 +513,53 @@ __global__ __launch_bounds__(PART_THREADS) void k_key_dedupe3(const unsigned lon
         const unsigned long long cap = bucket_off[b + 1] - off;
         cnt = (uint32_t)min((unsigned long long)cursor[b], cap);     // (an overflowed bucket is clamped; the step is redone)
     };
-    auto fetch = [&](uint32_t cnt, unsigned long long off) {
+    uint64_t nx[DD3_UNR];
+    auto fetch = [&](uint32_t cnt, unsigned long long off, uint32_t chunk) {
         const unsigned long long* in = rec + off;
 #pragma unroll
-        for (int u = 0; u < DD3_UNR; ++u) nx[u] = (tid + PART_THREADS * u) < cnt ? in[tid + PART_THREADS * u] : SAGE_SET_EMPTY;
+        for (int u = 0; u < DD3_UNR; ++u) {
+            const uint32_t i = chunk * CHUNK + tid + PART_THREADS * u;
+            const unsigned long long* src = i < cnt ? in + i : rec;
+            nx[u] = *src;
+        }
     };
-    uint32_t bk = blockIdx.x;
-    uint32_t cnt0, cnt1, cnt2;
+    // current item (bucket b0 of cnt0 records at off0, pass p of `passes`, chunk), the two buckets after it
+    uint32_t b0 = blockIdx.x, cnt0, cnt1, cnt2, p = 0, chunk = 0;
     unsigned long long off0, off1, off2;
-    meta(bk, cnt0, off0);
-    meta(bk + gridDim.x, cnt1, off1);
-    fetch(cnt0, off0);
-    for (; bk < n_buckets; bk += gridDim.x) {
+    meta(b0, cnt0, off0);
+    meta(b0 + gridDim.x, cnt1, off1);
+    meta(b0 + 2u * gridDim.x, cnt2, off2);
+    auto next_bucket = [&]() {       // (uniform) shifts the bucket window by one, skipping empty buckets
+        do {
+            b0 += gridDim.x;
+            cnt0 = cnt1; off0 = off1; cnt1 = cnt2; off1 = off2;
+            meta(b0 + 2u * gridDim.x, cnt2, off2);
+        } while (b0 < n_buckets && cnt0 == 0u);
+        p = 0; chunk = 0;
+    };
+    if (b0 < n_buckets && cnt0 == 0u) next_bucket();
+    if (b0 < n_buckets) fetch(cnt0, off0, 0u);
+    while (b0 < n_buckets) {
         uint64_t cur[DD3_UNR];
 #pragma unroll
         for (int u = 0; u < DD3_UNR; ++u) cur[u] = nx[u];
-        meta(bk + 2u * gridDim.x, cnt2, off2);
-        fetch(cnt1, off1);                              // the next bucket's records travel while this one is inserted
-        const uint32_t cnt = cnt0;
-        const unsigned long long* in = rec + off0;
-        cnt0 = cnt1; off0 = off1; cnt1 = cnt2; off1 = off2;
-        if (cnt == 0) continue;
-        if (tid == 0) n_read += cnt;
-        const uint32_t passes = (cnt + SET3_FILL - 1u) / SET3_FILL;
-        for (uint32_t p = 0; p < passes; ++p) {
-            __syncthreads();
+        // this item
+        const uint32_t cnt = cnt0, passes = (cnt0 + SET3_FILL - 1u) / SET3_FILL, my_p = p, my_chunk = chunk;
+        // the next item, and its loads
+        if ((chunk + 1u) * CHUNK < cnt0) ++chunk;
+        else if (p + 1u < passes) { ++p; chunk = 0; }
+        else next_bucket();
+        if (b0 < n_buckets) fetch(cnt0, off0, chunk);
+        if (my_chunk == 0u) {            // a new (bucket, pass): every thread is done with the set's previous contents
+            if (tid == 0 && my_p == 0u) n_read += cnt;
+            lds_barrier();
             for (uint32_t i = tid; i < SET3_SLOTS; i += PART_THREADS) set3[i] = SAGE_SET_EMPTY;
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < DD3_UNR; ++u)
-                if (cur[u] != SAGE_SET_EMPTY && (passes == 1u || (sage_key_hash_a(cur[u]) >> 14) % passes == p))
-                    n_distinct += lds_set3_insert(set3, cur[u], flags);
-            for (uint32_t i = tid + PART_THREADS * DD3_UNR; i < cnt; i += PART_THREADS) {   // an oversized bucket's tail
-                const uint64_t k = in[i];
-                if (passes == 1u || (sage_key_hash_a(k) >> 14) % passes == p) n_distinct += lds_set3_insert(set3, k, flags);
-            }
+            lds_barrier();
         }
+#pragma unroll
+        for (int u = 0; u < DD3_UNR; ++u)
+            if (my_chunk * CHUNK + tid + PART_THREADS * u < cnt && (passes == 1u || (sage_key_hash_a(cur[u]) >> 14) % passes == my_p))
+                n_distinct += lds_set3_insert(set3, cur[u], flags);
     }
 #pragma unroll
     for (int dd = 32; dd >= 1; dd >>= 1) n_distinct += __shfl_down(n_distinct, dd, 64);
