@@ -162,9 +162,9 @@ def algorithmic_bytes(st, dim, uniq=None):
     if e == 8:        # float64 storage: one score kernel over everything
         occ_fix = rows_fix = rows_f64 = 0
     return {
-        "match": nb * (1 + 1 + 8),                              # text + rem read, 8-byte match entry written, per byte
-        "walk": tok * 8 * 2 + tok * 12,                         # M entry of every token read by both passes; token arrays out
-        "describe": st["rows"] * 8 + occ * 64,                  # 8 B of M per window/span element, 64-byte descriptor out
+        "match": nb * (1 + 1 + 4),                              # text + rem read, 4-byte match entry written, per byte
+        "walk": tok * 4 * 2 + tok * 12,                         # M entry of every token read by both passes; token arrays out
+        "describe": st["rows"] * 4 + occ * 64,                  # 4 B of M per window/span element, 64-byte descriptor out
         "partition": occ * 64 + st["pairs"] * 8,                # descriptors in, one 8-byte record per position pair out
         "count": st["pairs"] * 8,                               # every record read once
         "pairs": tok * (dim * e + 16),                          # one row per token, 16-byte pair-cache entry out

@@ -99,7 +99,7 @@ int sage_tokenize(sage_ctx* ctx, int64_t line_begin, int64_t line_end, int32_t* 
  * resident vocabulary, harnesses that forbid hipMalloc, code that runs between the captures of a HIP graph (the call
  * itself synchronises the stream and copies two small results to the host, so it cannot be CAPTURED).  It allocates and frees no
  * device memory: its scratch (text copy with its zero pad, line remainders, the match table, per-line counters)
- * lives in a static device array of ~10.6 MiB that every GPU the library runs on holds until the process ends.
+ * lives in a static device array of ~6.6 MiB that every GPU the library runs on holds until the process ends.
  * Inputs and outputs are the CALLER's DEVICE buffers: d_text[n_bytes] holds the lines back to back, d_line_offsets
  * [n_lines + 1] their byte offsets (int64, from 0 to n_bytes); d_ids/d_starts/d_widths[capacity] (all three or none)
  * and d_counts[n_lines] (optional) receive what sage_tokenize returns; *out_total (host) = number of tokens.  The

@@ -78,6 +78,7 @@ SAGE_HD uint32_t sage_key_hash_b(uint64_t k) {
 #define SAGE_T_ID(w) ((w) & SAGE_ID_MASK)
 #define SAGE_T_LOC3(w) (((w) >> 20) & 3u)
 #define SAGE_T_AFTER3(w) (((w) >> 22) & 3u)
+#define SAGE_T_LEN(w) (((w) >> 24) & 0x3Fu)    /* width of the token in bytes */
 
 // Occurrence descriptor: 16 u32 per base token.  word 0 = header, words 1.. = the ablated window
 // [left pads | x1..xk | right pads] (at most SAGE_DESC_MAXWIN ids, otherwise OVER is set and the slow path runs).

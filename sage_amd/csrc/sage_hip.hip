@@ -42,15 +42,15 @@ constexpr size_t NA_ALIGN = 256;
 constexpr size_t na_up(size_t x) { return (x + NA_ALIGN - 1) / NA_ALIGN * NA_ALIGN; }
 constexpr size_t NA_TEXT = 0;                                                          // text + 1 KiB zero pad
 constexpr size_t NA_REM = NA_TEXT + na_up(SAGE_NOALLOC_MAX_BYTES + 1024);              // bytes to the line end
-constexpr size_t NA_M = NA_REM + na_up(SAGE_NOALLOC_MAX_BYTES + 1024);                 // match table, 8 B per byte
-constexpr size_t NA_NTOK = NA_M + na_up((size_t)SAGE_NOALLOC_MAX_BYTES * 8);
+constexpr size_t NA_M = NA_REM + na_up(SAGE_NOALLOC_MAX_BYTES + 1024);                 // match table, 4 B per byte
+constexpr size_t NA_NTOK = NA_M + na_up((size_t)SAGE_NOALLOC_MAX_BYTES * 4);
 constexpr size_t NA_NOCC = NA_NTOK + na_up((size_t)SAGE_NOALLOC_MAX_LINES * 4);
 constexpr size_t NA_TOKOFF = NA_NOCC + na_up((size_t)SAGE_NOALLOC_MAX_LINES * 4);
 constexpr size_t NA_OCCOFF = NA_TOKOFF + na_up(((size_t)SAGE_NOALLOC_MAX_LINES + 1) * 4);
 constexpr size_t NA_TILES = NA_OCCOFF + na_up(((size_t)SAGE_NOALLOC_MAX_LINES + 1) * 4);
 constexpr size_t NA_TOTAL = NA_TILES + na_up(((size_t)SAGE_NOALLOC_MAX_LINES / SCAN_TILE + 2) * 4);
 constexpr size_t NA_FLAGS = NA_TOTAL + na_up(16);
-constexpr size_t NA_BYTES = NA_FLAGS + na_up(FLAG_COUNT * 4);                           // ~10.6 MiB
+constexpr size_t NA_BYTES = NA_FLAGS + na_up(FLAG_COUNT * 4);                           // ~6.6 MiB
 static __device__ __align__(256) unsigned char scratch[NA_BYTES];
 
 struct sage_ctx {
@@ -63,7 +63,7 @@ struct sage_ctx {
     // vocabulary
     DevBuf buckets, keys, byte_id, direct2, bloom, pmask, pmask8, ebk, parent;
     DevBuf parent_old, old_to_new, remap;   // sage_set_vocab_pruned: the previous vocabulary's parents, its id map, the match remap
-    // The match table of the WHOLE resident corpus (8 B per byte), kept across steps when it fits m_resident_max: a
+    // The match table of the WHOLE resident corpus (4 B per byte), kept across steps when it fits m_resident_max: a
     // vocabulary that only lost keys (what SaGe does between steps) then needs no matching at all -- every match moves
     // to its nearest surviving prefix, a table lookup per corpus byte (sage_set_vocab_pruned).
     bool m_whole = false;      // M covers the whole corpus (indexed by absolute position) rather than one batch
@@ -250,7 +250,7 @@ struct MatchBufs {
     const uint8_t* corpus;      // text, readable up to 1 KiB past its last byte
     const uint8_t* rem;         // bytes to the line end per text byte
     const int64_t* line_off;    // device line offsets, indexed from line 0 of `corpus`
-    uint2* M;                   // [nb]
+    uint32_t* M;                // [nb]
     uint32_t *ntok, *nocc;      // [nl]
     uint32_t *tokoff, *occoff;  // [nl + 1]
     uint32_t* tile_sums;        // [scan_tiles(nl)]
@@ -298,7 +298,7 @@ void launch_match_and_count(sage_ctx* c, const MatchBufs& B, int64_t line0, uint
 }
 
 // M of the batch that starts at corpus position pos0
-inline uint2* batch_M(const sage_ctx* c, int64_t pos0) { return c->M.as<uint2>() + (c->m_whole ? pos0 : 0); }
+inline uint32_t* batch_M(const sage_ctx* c, int64_t pos0) { return c->M.as<uint32_t>() + (c->m_whole ? pos0 : 0); }
 
 // The same over lines [line0, line1) of the resident corpus, into the context's buffers.  out_total (optional) syncs.
 int match_and_count(sage_ctx* c, int64_t line0, int64_t line1, uint64_t* out_total) {
@@ -307,7 +307,7 @@ int match_and_count(sage_ctx* c, int64_t line0, int64_t line1, uint64_t* out_tot
     const uint32_t nl = (uint32_t)(line1 - line0);
     if (nb >= 0xFFFFFF00ull) return fail(c, SAGE_E_LIMIT, "a batch must stay under 4 GiB of corpus bytes");
     int rc;
-    if ((rc = ensure(c, c->M, std::max<uint64_t>(c->m_whole ? (uint64_t)c->nbytes : nb, 1) * sizeof(uint2)))) return rc;
+    if ((rc = ensure(c, c->M, std::max<uint64_t>(c->m_whole ? (uint64_t)c->nbytes : nb, 1) * sizeof(uint32_t) + 16))) return rc;
     if ((rc = ensure(c, c->ntok, (size_t)nl * 4))) return rc;
     if ((rc = ensure(c, c->nocc, (size_t)nl * 4))) return rc;
     if ((rc = ensure(c, c->tokoff, ((size_t)nl + 1) * 4))) return rc;
@@ -535,7 +535,8 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
                     c->occ_tok.as<uint32_t>(), nullptr, nullptr, nullptr);
             }
             if (n_occ == 0) { HIP_TRY(c, hipGetLastError()); sa = sb; continue; }
-            WalkArrays A{batch_M(c, pos0), (uint32_t)(c->h_line_off[line1] - pos0), c->tok_w0.as<uint32_t>(), c->occ_pos.as<uint32_t>()};
+            WalkArrays A{batch_M(c, pos0), (uint32_t)(c->h_line_off[line1] - pos0), c->tok_w0.as<uint32_t>(), c->occ_pos.as<uint32_t>(),
+                         c->parent.as<uint32_t>()};
             if ((rc = ensure(c, c->set_base, (size_t)nsb * 8))) return rc;
             if ((rc = ensure(c, c->set_mask, (size_t)nsb * 8))) return rc;
             if ((rc = ensure(c, c->seg_pairs, (size_t)nsb * 8))) return rc;
@@ -1045,7 +1046,7 @@ int sage_set_vocab_pruned(sage_ctx* c, const uint8_t* key_bytes, const int64_t* 
     {
         Prof p(c, SAGE_K_MATCH);       // what replaces the matcher on this step
         k_remap_matches<<<(uint32_t)std::min<uint64_t>(((uint64_t)c->nbytes + 255) / 256, (uint64_t)c->n_cu * 32u), 256, 0, c->stream>>>(
-            c->M.as<uint2>(), (uint64_t)c->nbytes, c->remap.as<uint32_t>(), (uint32_t)n_old, c->parent.as<uint32_t>(), c->flags.as<uint32_t>());
+            c->M.as<uint32_t>(), (uint64_t)c->nbytes, c->remap.as<uint32_t>(), (uint32_t)n_old, c->flags.as<uint32_t>());
     }
     HIP_TRY(c, hipGetLastError());
     uint32_t flags[FLAG_COUNT];
@@ -1082,7 +1083,7 @@ int sage_set_corpus(sage_ctx* c, const uint8_t* bytes, const int64_t* line_offse
     c->n_lines = n_lines;
     c->nbytes = nbytes;
     c->m_valid = false;
-    c->m_whole = nbytes > 0 && nbytes * 8 <= c->m_resident_max;
+    c->m_whole = nbytes > 0 && nbytes * 4 <= c->m_resident_max;
     if (nbytes) {
         k_line_remaining<<<(uint32_t)std::min<uint64_t>(((uint64_t)nbytes + 255) / 256, 1u << 20), 256, 0, c->stream>>>(
             c->line_off.as<int64_t>(), n_lines, c->rem.as<uint8_t>(), nbytes);
@@ -1370,7 +1371,7 @@ int sage_tokenize_noalloc(sage_ctx* c, const uint8_t* d_text, int64_t n_bytes, c
     unsigned char* S = c->na_scratch;          // never the array's name: see the note at its definition
     uint8_t* text = S + NA_TEXT;
     uint8_t* rem = S + NA_REM;
-    const MatchBufs B{text, rem, d_line_offsets, reinterpret_cast<uint2*>(S + NA_M),
+    const MatchBufs B{text, rem, d_line_offsets, reinterpret_cast<uint32_t*>(S + NA_M),
                       reinterpret_cast<uint32_t*>(S + NA_NTOK), reinterpret_cast<uint32_t*>(S + NA_NOCC),
                       reinterpret_cast<uint32_t*>(S + NA_TOKOFF), reinterpret_cast<uint32_t*>(S + NA_OCCOFF),
                       reinterpret_cast<uint32_t*>(S + NA_TILES), reinterpret_cast<uint64_t*>(S + NA_TOTAL),

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void k_line_remaining(const int64_t* __restric
 // ----------------------------------------------------------------------------------------------------------
 template <int NW>  // key words of 8 bytes: handles max_len <= 8*NW
 __global__ __launch_bounds__(256) void k_match(const uint8_t* __restrict__ corpus, const uint8_t* __restrict__ rem,
-                                               int64_t pos0, uint32_t count, VocabDev v, uint2* __restrict__ M) {
+                                               int64_t pos0, uint32_t count, VocabDev v, uint32_t* __restrict__ M) {
     constexpr int ML = 8 * NW;
     constexpr int NDW = (256 + ML + 8) / 4 + 1;
     __shared__ uint32_t text[NDW];
@@ -150,7 +150,8 @@ __global__ __launch_bounds__(256) void k_match(const uint8_t* __restrict__ corpu
         if (hit) { id2 = id1; len2 = len1; id1 = hid; len1 = (uint32_t)j; }
     }
     const uint32_t ends1 = len1 == (uint32_t)rem[blk0 + tid] ? 0x80000000u : 0u;
-    M[rel] = make_uint2(id1 | (len1 << 20) | ends1, id2 | (len2 << 20));
+    (void)id2; (void)len2;      // the second match is the parent of the first (k_vocab_parents): not stored
+    M[rel] = id1 | (len1 << 20) | ends1;
 }
 
 // ----------------------------------------------------------------------------------------------------------
@@ -616,26 +617,20 @@ __device__ __forceinline__ uint32_t remap_one(uint32_t m1, const uint32_t* __res
     const uint32_t nid = SAGE_M_ID(r), L = SAGE_M_LEN(r);
     return L == 0u ? (nid | (m1 & 0xFFF00000u)) : (nid | (L << 20));      // a shorter match cannot end the line
 }
-// four positions per thread and iteration: two 16-byte loads, the eight table lookups in flight together, two 16-byte stores
-__global__ __launch_bounds__(256) void k_remap_matches(uint2* __restrict__ M, uint64_t n_pos, const uint32_t* __restrict__ remap,
-                                                       uint32_t n_old, const uint32_t* __restrict__ parent_new,
-                                                       uint32_t* __restrict__ flags) {
+// four positions per thread and iteration: one 16-byte load, the four table lookups in flight together, one 16-byte store
+__global__ __launch_bounds__(256) void k_remap_matches(uint32_t* __restrict__ M, uint64_t n_pos, const uint32_t* __restrict__ remap,
+                                                       uint32_t n_old, uint32_t* __restrict__ flags) {
     bool bad = false;
     const uint64_t n4 = n_pos / 4u;
     uint4* M4 = reinterpret_cast<uint4*>(M);
     for (uint64_t q = (uint64_t)blockIdx.x * 256u + threadIdx.x; q < n4; q += (uint64_t)gridDim.x * 256u) {
-        const uint4 a = M4[2 * q], b = M4[2 * q + 1];             // (x, y) of positions 4q .. 4q+3
-        const uint32_t x0 = remap_one(a.x, remap, n_old, bad), x1 = remap_one(a.z, remap, n_old, bad);
-        const uint32_t x2 = remap_one(b.x, remap, n_old, bad), x3 = remap_one(b.z, remap, n_old, bad);
-        const uint32_t y0 = parent_new[SAGE_M_ID(x0)], y1 = parent_new[SAGE_M_ID(x1)];
-        const uint32_t y2 = parent_new[SAGE_M_ID(x2)], y3 = parent_new[SAGE_M_ID(x3)];
-        M4[2 * q] = make_uint4(x0, y0, x1, y1);
-        M4[2 * q + 1] = make_uint4(x2, y2, x3, y3);
+        const uint4 a = M4[q];
+        M4[q] = make_uint4(remap_one(a.x, remap, n_old, bad), remap_one(a.y, remap, n_old, bad),
+                           remap_one(a.z, remap, n_old, bad), remap_one(a.w, remap, n_old, bad));
     }
     if (blockIdx.x == 0 && threadIdx.x < (uint32_t)(n_pos - 4u * n4)) {
         const uint64_t p = 4u * n4 + threadIdx.x;
-        const uint32_t x = remap_one(M[p].x, remap, n_old, bad);
-        M[p] = make_uint2(x, parent_new[SAGE_M_ID(x)]);
+        M[p] = remap_one(M[p], remap, n_old, bad);
     }
     if (bad) flags[FLAG_SET_OVERFLOW] = 1;
 }
@@ -644,7 +639,7 @@ __global__ __launch_bounds__(256) void k_remap_matches(uint2* __restrict__ M, ui
 // for max_len 17 hashes 16 prefix lengths, not the 23 a 24-byte window would allow.
 template <int NW, int ML = 8 * NW, bool QUEUED = true>
 __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ corpus, const uint8_t* __restrict__ rem,
-                                                    int64_t pos0, uint32_t count, VocabDev v, uint2* __restrict__ M) {
+                                                    int64_t pos0, uint32_t count, VocabDev v, uint32_t* __restrict__ M) {
     static_assert(ML <= 8 * NW && ML > 8 * (NW - 1), "ML must need exactly NW key words");
     constexpr int WDW = (64 + ML + 8) / 4 + 1;   // dwords of text one wave stages for its 64 positions (<= 27)
     __shared__ uint32_t bloom[SAGE_BLOOM_BITS / 32];
@@ -748,17 +743,14 @@ if constexpr (ML >= 9) {
             if (__any((c2 & 0x0Cu) != 0u)) probe_chunk<NW, 3, 4, ML>(v, c2, fh, W, top);
         }
         if constexpr (QUEUED) {
-            // The queued classes stop at a lane's first hit (the longest match).  A class that found two has the second
-            // longest too (nothing lies between them outside the class); otherwise it is the parent of the longest: one
-            // lookup in a 1 MiB table instead of the probes of every shorter candidate length.
+            // The queued classes stop at a lane's first hit: the longest match is all the table keeps (the second longest
+            // match at a position is the parent of the longest, which its one reader looks up in k_vocab_parents' table).
             if (top.m1 == 0u) {
                 // no key of 3+ bytes: 2-byte keys need no hash (a 256 KiB table indexed by the two bytes), and the single
                 // byte always matches -- the longest match when nothing else hit, the second when the 2-byte key did
                 if (lim >= 2u) d2 = v.direct2[T[0] & 0xFFFFu];
                 top.fold((lim >= 2u && d2 != SAGE_SLOT_EMPTY) ? (d2 | (2u << 20)) : 0u);
                 top.fold(v.byte_id[T[0] & 0xFFu] | (1u << 20));
-            } else if (top.m2 == 0u) {
-                top.m2 = v.parent[SAGE_M_ID(top.m1)];
             }
         } else {
             // 2-byte keys need no hash: a 256 KiB table indexed by the two bytes
@@ -767,12 +759,10 @@ if constexpr (ML >= 9) {
             // the single byte always matches: it is the longest match when nothing else hit, the second when one did
             if (top.m2 == 0u) top.fold(v.byte_id[T[0] & 0xFFu] | (1u << 20));
         }
-        // (more than two matches may have been folded in -- a chunk probes all its lengths -- m1 and m2 are the two
-        // longest of them in any case; with a single match m2 is 0 = "no second match", len2 == 0 iff len1 == 1)
+        // (more than one match may have been folded in -- a chunk probes all its lengths -- m1 is the longest in any case)
         // streamed once: keep it out of the way of the table and key planes in L2
         const uint32_t ends1 = SAGE_M_LEN(top.m1) == rm ? 0x80000000u : 0u;
-        if (rel < count)
-            __builtin_nontemporal_store((uint64_t)(top.m1 | ends1) | ((uint64_t)top.m2 << 32), reinterpret_cast<uint64_t*>(M + rel));
+        if (rel < count) __builtin_nontemporal_store(top.m1 | ends1, M + rel);
     }
 }
 
@@ -781,7 +771,7 @@ if constexpr (ML >= 9) {
 // (after an exclusive scan of the counts) writes the compact token arrays.
 // ----------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_walk_count(const int64_t* __restrict__ line_off, int64_t line0,
-                                                    uint32_t n_lines, int64_t pos0, const uint2* __restrict__ M,
+                                                    uint32_t n_lines, int64_t pos0, const uint32_t* __restrict__ M,
                                                     uint32_t* __restrict__ ntok, uint32_t* __restrict__ nocc,
                                                     uint32_t* __restrict__ flags) {
     uint32_t l = blockIdx.x * 256u + threadIdx.x;
@@ -790,7 +780,7 @@ __global__ __launch_bounds__(256) void k_walk_count(const int64_t* __restrict__ 
     if (p == e) flags[FLAG_EMPTY_LINE] = 1;
     uint32_t c = 0, mb = 0;
     while (p < e) {
-        const uint32_t len = SAGE_M_LEN(M[p].x);
+        const uint32_t len = SAGE_M_LEN(M[p]);
         p += len; ++c; mb += len > 1u;
     }
     ntok[l] = c;
@@ -827,7 +817,7 @@ struct GroupedWriter {
 
 template <bool EXPORT>
 __global__ __launch_bounds__(256) void k_walk_write(const int64_t* __restrict__ line_off, int64_t line0,
-                                                    uint32_t n_lines, int64_t pos0, const uint2* __restrict__ M,
+                                                    uint32_t n_lines, int64_t pos0, const uint32_t* __restrict__ M,
                                                     const uint32_t* __restrict__ tok_off,
                                                     const uint32_t* __restrict__ occ_off,
                                                     uint32_t* __restrict__ tok_w0, uint32_t* __restrict__ occ_pos,
@@ -844,14 +834,14 @@ __global__ __launch_bounds__(256) void k_walk_write(const int64_t* __restrict__ 
     GroupedWriter gw_tok, gw_occ, gw_pos;
     if (!EXPORT) { gw_tok.init(tok_w0, t); gw_occ.init(occ_tok, o); gw_pos.init(occ_pos, o); }
     while (p < e) {
-        const uint32_t m = M[p].x;
+        const uint32_t m = M[p];
         if (EXPORT) {
             ex_ids[t] = (int32_t)SAGE_M_ID(m);
             ex_starts[t] = (int32_t)(p - p_begin);
             ex_widths[t] = (int32_t)SAGE_M_LEN(m);
         } else {
             const uint32_t after = nt - 1u - c;
-            gw_tok.put(t, SAGE_M_ID(m) | ((c < 3u ? c : 3u) << 20) | ((after < 3u ? after : 3u) << 22));
+            gw_tok.put(t, SAGE_M_ID(m) | ((c < 3u ? c : 3u) << 20) | ((after < 3u ? after : 3u) << 22) | (SAGE_M_LEN(m) << 24));
             if (SAGE_M_LEN(m) > 1u) { gw_occ.put(o, t); gw_pos.put(o, p); ++o; }   // compact list of the tokens that get ablated
         }
         p += SAGE_M_LEN(m);
@@ -954,10 +944,11 @@ __global__ void k_widen_counts(const uint32_t* __restrict__ src, uint32_t n, int
 
 // What the ablation walk (walk_occurrence, sage_kernels2.h) reads: the match table M and the compact token arrays.
 struct WalkArrays {
-    const uint2* M;
+    const uint32_t* M;        // longest match per position: id | len << 20 | (ends the line) << 31
     uint32_t n_pos;           // positions of the batch (entries of M)
-    const uint32_t* tok_w0;
+    const uint32_t* tok_w0;   // base tokens: id | min(index in line, 3) << 20 | min(tokens after it, 3) << 22 | width << 24
     const uint32_t* occ_pos;  // byte position of every ablated occurrence
+    const uint32_t* parent;   // [ids] longest proper prefix of a key that is a key, as id | len << 20 (k_vocab_parents)
 };
 
 // ----------------------------------------------------------------------------------------------------------

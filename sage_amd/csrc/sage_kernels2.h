@@ -156,7 +156,11 @@ struct OccWords { uint32_t w0, prev1, prev2; uint2 m0; };
 __device__ __forceinline__ OccWords load_occ_words(const WalkArrays& A, uint32_t t, uint32_t p0) {
     OccWords w;
     w.w0 = A.tok_w0[t];
-    w.m0 = A.M[p0];
+    // the token's own match entry from its token word, its second-longest match = the parent of the longest: a lookup in a
+    // 1 MiB table instead of a second 4-byte column of the match table
+    (void)p0;
+    w.m0 = make_uint2(SAGE_T_ID(w.w0) | (SAGE_T_LEN(w.w0) << 20) | (SAGE_T_AFTER3(w.w0) == 0u ? 0x80000000u : 0u),
+                      A.parent[SAGE_T_ID(w.w0)]);
     w.prev1 = t >= 1u ? A.tok_w0[t - 1] : 0u;     // used only when the token has that many predecessors in its line
     w.prev2 = t >= 2u ? A.tok_w0[t - 2] : 0u;
     return w;
@@ -309,7 +313,7 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
 #pragma unroll
             for (uint32_t q = 0; q < DESC_SPAN / 256u; ++q) {
                 const uint32_t i = threadIdx.x + 256u * q;
-                sp[q] = (P0 + i) < A.n_pos ? A.M[P0 + i].x : 0u;
+                sp[q] = (P0 + i) < A.n_pos ? A.M[P0 + i] : 0u;
             }
             if (live) ow = load_occ_words(A, t_pre, p0_pre);
             first_level(base + gridDim.x * 256u);
@@ -321,7 +325,7 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
         auto ldx = [&](uint32_t p) -> uint32_t {
             const uint32_t d = p - P0;
             if (!LONG && d < (uint32_t)DESC_SPAN) return span[d];
-            return A.M[p].x;
+            return A.M[p];
         };
         const uint32_t t = LONG ? (live ? occ_tok[o] : 0u) : t_pre;
         const uint32_t p0 = LONG ? (live ? A.occ_pos[o] : 0u) : p0_pre;
