@@ -343,13 +343,17 @@ def main():
         ranked = sorted((v, k) for k, v in scored.items())
         doomed = {model.id_to_bytes(t) for _, t in ranked[:len(scored) - target]}
         survivors = [k for k in vocab if k not in doomed]
-        keep_old_ids = np.array([i for i, k in enumerate(vocab) if k not in doomed], dtype=np.int64)
         # Two matrices, as a schedule meets them: STALE = the matrix of the unpruned vocabulary read with the re-compacted
         # ids, which is what the reference does between two retrain labels (SaGeVocabBuilder.py:89-91,192: ids move,
         # rows do not) -- other ids now meet the float64 uniform rows, most windows touch one and the float32 copy stops
-        # paying; FRESH = rows in the order of the new ids, what a step right after a retrain label sees.
+        # paying; FRESH = what a retrain at this label leaves (embeddings.py:77-89): float32-valued rows for the tokens
+        # the PRUNED vocabulary's tokenization of the corpus produces, the float64 uniform draw for the rest.
+        model.set_vocabulary(survivors)
+        parallel.sync_vocab(eng, model)
+        seen_after = np.bincount(eng.tokenize(0, eng.n_lines)[0], minlength=len(survivors)) > 0
+        emb_fresh = synth.make_embeddings(len(survivors), args.dim, seed=seed + 1, unseen=~seen_after)
         res = {}
-        for matrix, E in (("stale_matrix", emb), ("fresh_matrix", np.ascontiguousarray(emb[keep_old_ids]))):
+        for matrix, E in (("stale_matrix", emb), ("fresh_matrix", emb_fresh)):
             res[matrix] = {}
             for mode, incr in (("carried_matches", "1"), ("rematched", "0")):
                 model.set_vocabulary(vocab)
