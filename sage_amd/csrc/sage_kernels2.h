@@ -721,8 +721,10 @@ __device__ __forceinline__ void dots_body(const uint4* __restrict__ desc, const 
             if (gl == 0u) tk = atomicAdd(&next_occ, 1u);
             tk = __shfl(tk, (int)((threadIdx.x & 63u) & ~(uint32_t)(G - 1)), 64);       // (the group's lanes branch together)
         }
-        const unsigned long long at = ((unsigned long long)(tk / DOTS_WIN) * gridDim.x + blockIdx.x) * DOTS_WIN + tk % DOTS_WIN;
-        fi = at < (unsigned long long)n ? (uint32_t)at : n;
+        // (32-bit: a batch holds fewer than 2^32 bytes, hence fewer than 2^31 occurrences of 2+ bytes, and a group draws at
+        // most one ticket past the end of the list)
+        const uint32_t at = (tk / DOTS_WIN * gridDim.x + blockIdx.x) * DOTS_WIN + tk % DOTS_WIN;
+        fi = at < n ? at : n;
     };
     next_index();
     const uint32_t* fids = nullptr;

@@ -202,6 +202,52 @@ def test_step_vs_oracle(style, max_len, dim):
         eng.close()
 
 
+@pytest.mark.parametrize("dim,score_mode", [(50, 0), (50, 1), (300, 0)])
+def test_tiny_lines_vs_oracle(dim, score_mode):
+    """Lines of one to three words plus empty-ish ones: ablated windows of two elements (no pads at all), occurrences at
+    both ends of a line, a group of the dots kernel opening a new occurrence every other step (the two-stage prefetch
+    of the next occurrence's words is not ready then and the in-branch loads serve), one-token lines for the walks."""
+    from oracle import sage_oracle as orc
+    from sage_amd import synth
+    from sage_amd.parallel import segment_line_bounds
+    base, boff = synth.make_corpus(300, seed=321 + dim, style="en", n_types=400, mean_log_words=2.5)
+    vocab = synth.make_vocab(base, boff, 900, 12, sample_bytes=200_000)
+    words = [w for ln in synth.corpus_lines(base, boff) for w in ln.split()]
+    rs = np.random.RandomState(5)
+    lines, at = [], 0
+    while at < len(words) and len(lines) < 1500:
+        k = int(rs.choice([1, 1, 2, 2, 3]))
+        lines.append(" ".join(words[at:at + k]) if rs.rand() > 0.03 else words[at][:1])      # (some one-character lines)
+        at += k
+    assert sum(1 for l in lines if len(l) <= 8) > 100
+    corpus, off = _pack(lines)
+    counts = {}
+    tok = orc.OracleTokenizer(vocab, 12)
+    for ln in lines:
+        for i, _, _ in tok.tokenize(ln):
+            counts[i] = counts.get(i, 0) + 1
+    unseen = np.array([i not in counts for i in range(len(vocab))])
+    emb = synth.make_embeddings(len(vocab), dim, seed=9, unseen=unseen)
+    occs = {}
+    losses, sizes, tt, ttr = {}, {}, 0, 0
+    for lo, hi in orc.shard_bounds(len(lines), 3):
+        l, t, r, sz = orc.run_shard(tok, lines[lo:hi], emb, flush=211, occurrences=occs)
+        tt += t; ttr += r
+        for k, v in l.items():
+            losses[k] = losses.get(k, 0) + v
+        for k, v in sz.items():
+            sizes[k] = sizes.get(k, 0) + v
+    eng = _engine()
+    eng.set_score_mode(score_mode)
+    eng.set_vocab(vocab, None, 12)
+    eng.set_corpus(corpus, off)
+    eng.set_embeddings(emb)
+    _check_step(eng, segment_line_bounds(len(lines), 3, flush=211), tt, ttr, losses, sizes, want_occ=occs)
+    eng.set_batch_bytes(4096)
+    _check_step_once(eng, segment_line_bounds(len(lines), 3, flush=211), tt, ttr, losses, sizes, want_occ=occs)
+    eng.close()
+
+
 @pytest.mark.parametrize("kind,dim", [("f32_exact", 50), ("mixed", 50), ("f64_all", 50), ("mixed", 20), ("mixed", 100),
                                       ("mixed", 200), ("mixed", 300), ("mixed", 400)])
 def test_score_storage_modes(kind, dim):
