@@ -701,7 +701,10 @@ __device__ __forceinline__ void dots_body(const uint4* __restrict__ desc, const 
     __syncthreads();
     constexpr uint32_t DOTS_WIN = 256u / G < 32u ? 32u : 256u / G;
     const uint32_t fend = n;
-    uint32_t fi = 0, fj = 0, fL = 0, fpl = 0, fk = 0;
+    // The open occurrence: element index fj of fL; which elements take a dot with their predecessor / the one before it is two
+    // RANGES of fj (an element or its partner must lie in the centre [pl, pl + k), and k >= 2 always: an ablation has a
+    // first piece and at least one more): [max(pl, 1), pl + k] and [2, pl + k + 1].
+    uint32_t fi = 0, fj = 0, fL = 0, flo1 = 1, fspan1 = 0, fem1 = 0;
     auto next_index = [&]() {
         uint32_t tk = 0;
         if constexpr (MIXED) {
@@ -766,17 +769,17 @@ __device__ __forceinline__ void dots_body(const uint4* __restrict__ desc, const 
                 asm volatile("" : "+v"(hy), "+v"(hz));
             }
             const Win w = win_decode(hx, hz, 0u);
-            fL = w.L; fpl = w.pl; fk = w.k; fj = 0;
+            fL = w.L; fj = 0;
+            flo1 = w.pl == 2u ? 2u : 1u;
+            fspan1 = w.pl + w.k - flo1;
+            fem1 = w.pl + w.k - 1u;
             fids = w.pooled ? pool + hy : desc_w + (size_t)o * 16 + 1;
             out = ov;
             next_index();
             age = 0;
         }
         id = fids[fj];
-        // element fj is in the centre [pl, pl+k) iff (fj - pl) < k unsigned; the same for its two predecessors
-        const uint32_t u = fj - fpl;
-        const bool c = u < fk, c1 = (u - 1u) < fk, c2 = (u - 2u) < fk;
-        meta = 8u | (fj == 0u ? 4u : 0u) | ((fj >= 1u && (c || c1)) ? 1u : 0u) | ((fj >= 2u && (c || c2)) ? 2u : 0u);
+        meta = (fj == 0u ? 12u : 8u) | ((fj - flo1) <= fspan1 ? 1u : 0u) | ((fj - 2u) <= fem1 ? 2u : 0u);     // (unsigned compares)
         ++fj;
     };
     // dots leave eight at a time: lane i of the group keeps the i-th pending dot, one 64-byte store per eight dots
