@@ -285,16 +285,32 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t* __restrict__ bitmap = D.inexact;
     PH_DECL;
-    // the first level of a tile's loads (its occurrences' token and position, the start of its span) is fetched a tile
-    // ahead, so a tile starts at its second level: the span of M and the occurrences' own words
-    uint32_t nx_t = 0, nx_p0 = 0, nx_P0 = 0;
-    auto first_level = [&](uint32_t b) {
-        const uint32_t it = b + threadIdx.x;
-        nx_t = it < n_items ? occ_tok[it] : 0u;
-        nx_p0 = it < n_items ? A.occ_pos[it] : 0u;
-        nx_P0 = b < n_items ? A.occ_pos[b] : 0u;
+    // A tile's loads are three dependent levels: (A) its occurrences' token index and position and the start of its span,
+    // (B) each occurrence's token word and the two token words before it, (C) the parent of its token (= the second-longest
+    // match) and the span of M.  Level A runs two tiles ahead and level B one tile ahead, so every level's addresses arrived
+    // a whole tile ago and a tile starts with ONE batch of loads.  All of them are unconditional (clamped indices; the
+    // predicate is applied where the value is used): a branch around a load makes the compiler wait for everything in
+    // flight ("Reading the waits").
+    const uint32_t tile_stride = gridDim.x * 256u;
+    uint32_t a_t = 0, a_p0 = 0, a_P0 = 0;                                   // level A of tile + 2 strides
+    uint32_t b_t = 0, b_p0 = 0, b_P0 = 0, b_w0 = 0, b_prev1 = 0, b_prev2 = 0;   // levels A, B of tile + 1 stride
+    const uint32_t last_item = n_items ? n_items - 1u : 0u;
+    auto level_a = [&](uint32_t bb) {
+        a_t = occ_tok[min(bb + threadIdx.x, last_item)];
+        a_p0 = A.occ_pos[min(bb + threadIdx.x, last_item)];
+        a_P0 = A.occ_pos[min(bb, last_item)];
     };
-    if (!LONG) first_level(blockIdx.x * 256u);
+    auto level_b = [&]() {       // promotes level A's tile and issues its level B
+        b_t = a_t; b_p0 = a_p0; b_P0 = a_P0;
+        b_w0 = A.tok_w0[b_t];
+        b_prev1 = A.tok_w0[b_t >= 1u ? b_t - 1u : 0u];       // used only when the token has that many predecessors in its line
+        b_prev2 = A.tok_w0[b_t >= 2u ? b_t - 2u : 0u];
+    };
+    if (!LONG && n_items) {
+        level_a(blockIdx.x * 256u);
+        level_b();
+        level_a(blockIdx.x * 256u + tile_stride);
+    }
     for (uint32_t base = blockIdx.x * 256u; base < n_round; base += gridDim.x * 256u) {
         PH_START();
         const uint32_t item = base + threadIdx.x;
@@ -305,27 +321,31 @@ __global__ __launch_bounds__(256) void k_describe(WalkArrays A, const uint32_t* 
         if (!LONG) {
             // 256 consecutive occurrences cover ~1.5 KB of text; their walks stay within a few hundred bytes of it.
             // Every dependent step of a walk is then an LDS read instead of an L2 round trip.
-            // the occurrence's own loads are issued with the span's, not after the barrier
-            t_pre = nx_t;
-            p0_pre = nx_p0;
-            P0 = nx_P0;
+            t_pre = b_t;
+            p0_pre = b_p0;
+            P0 = b_P0;
+            ow.w0 = b_w0; ow.prev1 = b_prev1; ow.prev2 = b_prev2;
+            // level C of this tile first (it is what the tile waits for), then the other tiles' levels
             uint32_t sp[DESC_SPAN / 256u];
+            const uint32_t last_pos = A.n_pos ? A.n_pos - 1u : 0u;
 #pragma unroll
-            for (uint32_t q = 0; q < DESC_SPAN / 256u; ++q) {
-                const uint32_t i = threadIdx.x + 256u * q;
-                sp[q] = (P0 + i) < A.n_pos ? A.M[P0 + i] : 0u;
-            }
-            if (live) ow = load_occ_words(A, t_pre, p0_pre);
-            first_level(base + gridDim.x * 256u);
+            for (uint32_t q = 0; q < DESC_SPAN / 256u; ++q) sp[q] = A.M[min(P0 + threadIdx.x + 256u * q, last_pos)];
+            const uint32_t par = A.parent[SAGE_T_ID(ow.w0)];
+            level_b();
+            level_a(base + 2u * tile_stride);
+            ow.m0 = make_uint2(SAGE_T_ID(ow.w0) | (SAGE_T_LEN(ow.w0) << 20) | (SAGE_T_AFTER3(ow.w0) == 0u ? 0x80000000u : 0u), par);
 #pragma unroll
-            for (uint32_t q = 0; q < DESC_SPAN / 256u; ++q) span[threadIdx.x + 256u * q] = sp[q];
-            __syncthreads();
+            for (uint32_t q = 0; q < DESC_SPAN / 256u; ++q)
+                span[threadIdx.x + 256u * q] = (P0 + threadIdx.x + 256u * q) < A.n_pos ? sp[q] : 0u;
+            lds_barrier();       // (not __syncthreads(): the other tiles' loads stay in flight)
         }
         if (!LONG) PH_MARK(0);
         auto ldx = [&](uint32_t p) -> uint32_t {
             const uint32_t d = p - P0;
             if (!LONG && d < (uint32_t)DESC_SPAN) return span[d];
-            return A.M[p];
+            uint32_t v = A.M[p];
+            if (!LONG) asm volatile("" : "+v"(v));      // consumed inside the rare branch: the wait for it stays there
+            return v;
         };
         const uint32_t t = LONG ? (live ? occ_tok[o] : 0u) : t_pre;
         const uint32_t p0 = LONG ? (live ? A.occ_pos[o] : 0u) : p0_pre;
