@@ -506,3 +506,64 @@ def test_repeated_keys_overflow_estimated_buckets():
     eng.set_embeddings(emb)
     _check_step(eng, segment_line_bounds(len(lines), 1), tt, ttr, losses, sizes, want_occ=occs)
     eng.close()
+
+
+def _fuzz_case(seed):
+    """One random small configuration: vocabulary size and max_len, embedding width, line shapes (long, short, one
+    character), worker count and flush size, float32 or float64 row storage, batch size."""
+    from sage_amd import synth
+    rs = np.random.RandomState(seed)
+    max_len = int(rs.choice([2, 3, 4, 7, 11, 16, 23, 32]))
+    dim = int(rs.choice([1, 2, 3, 17, 50, 64, 129, 300, 512]))
+    n_vocab = int(rs.choice([300, 700, 2000, 5000]))
+    style = str(rs.choice(["en", "tr"]))
+    base, boff = synth.make_corpus(int(rs.choice([60, 150, 300])), seed=1000 + seed, style=style,
+                                   n_types=int(rs.choice([150, 800, 3000])), mean_log_words=float(rs.choice([1.8, 2.6, 3.4])))
+    vocab = synth.make_vocab(base, boff, n_vocab, max_len, sample_bytes=200_000)
+    lines = synth.corpus_lines(base, boff)
+    words = [w for ln in lines for w in ln.split()]
+    extra = []
+    for _ in range(int(rs.choice([0, 40, 200]))):           # short lines cut from the same text
+        at = int(rs.randint(0, max(1, len(words) - 3)))
+        extra.append(" ".join(words[at:at + int(rs.choice([1, 1, 2, 3]))]) if rs.rand() > 0.1 else words[at][:1])
+    lines = lines + extra
+    order = rs.permutation(len(lines))
+    lines = [lines[i] for i in order]
+    return dict(max_len=max_len, dim=dim, vocab=vocab, lines=lines, workers=int(rs.choice([1, 2, 3, 5])),
+                flush=int(rs.choice([7, 50, 1000])), score_mode=int(rs.choice([0, 1])), emb_seed=int(rs.randint(1, 1000)),
+                batch=int(rs.choice([0, 4096, 65536])))
+
+
+@pytest.mark.parametrize("seed", [s for s in range(20) if s != 2])      # (seed 2: a minute of oracle time)
+def test_fuzz_vs_oracle(seed):
+    """Nineteen random small configurations (seeded), every integer of the step exact and the losses within tolerance against
+    the oracle, through both distinct-count back ends."""
+    from oracle import sage_oracle as orc
+    from sage_amd import synth
+    from sage_amd.parallel import segment_line_bounds
+    c = _fuzz_case(seed)
+    tok = orc.OracleTokenizer(c["vocab"], c["max_len"])
+    counts = {}
+    for ln in c["lines"]:
+        for i, _, _ in tok.tokenize(ln):
+            counts[i] = counts.get(i, 0) + 1
+    unseen = np.array([i not in counts for i in range(len(c["vocab"]))])
+    emb = synth.make_embeddings(len(c["vocab"]), c["dim"], seed=c["emb_seed"], unseen=unseen)
+    occs, losses, sizes, tt, ttr = {}, {}, {}, 0, 0
+    for lo, hi in orc.shard_bounds(len(c["lines"]), c["workers"]):
+        l, t, r, sz = orc.run_shard(tok, c["lines"][lo:hi], emb, flush=c["flush"], occurrences=occs)
+        tt += t; ttr += r
+        for k, v in l.items():
+            losses[k] = losses.get(k, 0) + v
+        for k, v in sz.items():
+            sizes[k] = sizes.get(k, 0) + v
+    corpus, off = _pack(c["lines"])
+    eng = _engine()
+    eng.set_score_mode(c["score_mode"])
+    if c["batch"]:
+        eng.set_batch_bytes(c["batch"])
+    eng.set_vocab(c["vocab"], None, c["max_len"])
+    eng.set_corpus(corpus, off)
+    eng.set_embeddings(emb)
+    _check_step(eng, segment_line_bounds(len(c["lines"]), c["workers"], flush=c["flush"]), tt, ttr, losses, sizes, want_occ=occs)
+    eng.close()
