@@ -469,9 +469,9 @@ __global__ __launch_bounds__(256) void k_key_giant(const uint4* __restrict__ des
     }
 }
 
-// Double hashing (an odd step from the key's own hash), not linear probing: half of the records are repeats of keys that
-// are already in the set, and behind a cluster every repeat walks the cluster again while its wave waits (12.3 -> 9.7 ms
-// for the kernel).  Measured alternatives, all slower: the first probe of a thread's eight records in flight together
+// Double hashing (an odd step from the key's own hash), not linear probing: a bucket's set fills to half its slots (nearly
+// all records of a segment are distinct keys), and an insertion that lands in a cluster walks the cluster while its wave
+// waits (12.3 -> 9.7 ms for the kernel).  Measured alternatives, all slower: the first probe of a thread's eight records in flight together
 // (10.9 ms), every record of a thread probing in the same round, lanes that move on to their next record as soon as a
 // probe ends, a per-wave queue that probes the stragglers densely, a set split into 32-bit claim words + stored high
 // words, two half-full passes per bucket (11.9 ms).  Without the insertions the kernel takes 4.5 ms.
