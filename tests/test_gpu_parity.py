@@ -567,3 +567,27 @@ def test_fuzz_vs_oracle(seed):
     eng.set_embeddings(emb)
     _check_step(eng, segment_line_bounds(len(c["lines"]), c["workers"], flush=c["flush"]), tt, ttr, losses, sizes, want_occ=occs)
     eng.close()
+
+
+def test_oracle_at_twenty_thousand_lines():
+    """The largest size the Python oracle finishes in seconds (a pool of 8 processes, as the reference runs its workers):
+    20,000 lines of the bench corpus' language (10 MB, 1.85 M tokens, 65 M triples), a 65,536-key vocabulary, D = 50, W = 8
+    shards.  Every integer exact, every loss within tolerance -- at 50x the other oracle tests' size the step runs full
+    workgroups, multi-tile partitions and buckets of thousands of records."""
+    from oracle import sage_oracle as orc
+    from sage_amd import synth
+    from sage_amd.parallel import segment_line_bounds
+    n_lines, W = 20_000, 8
+    corpus, off = synth.make_corpus(n_lines, seed=synth.DEFAULT_SEED, style="en", n_types=50_000)
+    vocab = synth.make_vocab(corpus, off, 65_536, 16, sample_bytes=3_000_000)
+    eng = _engine()
+    eng.set_vocab(vocab, None, 16)
+    eng.set_corpus(corpus, off)
+    counts = np.bincount(eng.tokenize(0, n_lines)[0], minlength=len(vocab))
+    emb = synth.make_embeddings(len(vocab), 50, seed=77, unseen=~(counts > 0))
+    eng.set_embeddings(emb)
+    lines = synth.corpus_lines(corpus, off)
+    tok = orc.OracleTokenizer(vocab, 16)
+    tt, ttr, losses, sizes = orc.run_parallel(emb, lines, tok, W, processes=W)
+    _check_step(eng, segment_line_bounds(n_lines, W), tt, ttr, losses, sizes)
+    eng.close()
