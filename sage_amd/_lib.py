@@ -3,12 +3,14 @@
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 import numpy as np
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libsage_hip.so"
+# SAGE_LIB=<path> loads another build of the same library (development: A/B runs of a variant under tools/abl/)
+LIB_PATH = Path(os.environ["SAGE_LIB"]) if os.environ.get("SAGE_LIB") else _HERE / "libsage_hip.so"
 
 K_CLASSES = ("match", "walk", "scan", "count", "score", "misc", "describe", "pairs", "logsig", "fix", "partition")
 
