@@ -663,9 +663,9 @@ __global__ __launch_bounds__(256) void k_pair_cache(const uint32_t* __restrict__
 // k_dots: for every occurrence, the dot products E[w_j].E[w_j-1], E[w_j].E[w_j-2] of its ablated window that
 // do_triples counts (model.py:129-136), written back to back at dot_off[o].  Gather-bound: G lanes own one
 // occurrence and walk a continuous stream of rows across occurrence boundaries -- row j+2 and j+1 are always in
-// flight while row j is reduced, the next occurrence's header is loaded one occurrence ahead, and there is no
-// barrier in the loop, no LDS beyond one counter and no transcendental code in this kernel, so a CU keeps >100 KB of
-// row gathers outstanding.
+// flight while row j is reduced, the next occurrence's words come from a branch-free two-stage prefetch (below), and
+// there is no barrier in the loop, no LDS beyond one counter and no transcendental code in this kernel, so a CU keeps
+// >100 KB of row gathers outstanding -- provided nothing in the loop waits for ALL vector memory (`vmcnt(0)`).
 // ----------------------------------------------------------------------------------------------------------
 // MIXED (T = double, the float64 pass over the inexact list): only the rows marked in `bitmap` come from the float64
 // matrix; the other rows of such a window (all but one of its ~7, on average) come from the float32 copy `emb32` --
@@ -707,8 +707,7 @@ __device__ __forceinline__ void dots_body(const uint4* __restrict__ desc, const 
     for (int i = 0; i < NQ; ++i) { qm[i] = 0; qo[i] = 0; }
 #pragma unroll
     for (int i = 0; i < NI; ++i) qid[i] = 0;
-    // id side: fi = position (in the list, or plain index) of the next occurrence to open, foi = its index,
-    // nh = its header words (prefetched one occurrence ahead)
+    // id side: fi = position (in the list, or plain index) of the next occurrence to open
     // Occurrences are handed out in windows of 32 consecutive ones, the windows round-robin over the workgroups (the
     // chip as a whole reads one moving window of descriptors, offsets and dots), and inside its window a workgroup's
     // groups draw the next occurrence from an LDS counter as they finish: 22.9 -> 21.8 ms against a fixed round-robin
