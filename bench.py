@@ -94,6 +94,7 @@ def roofline_object(dom, avg_ms, launches_per_step, per_kernel_bytes, named_byte
                    "row is counted every time (a delivery rate, not a fraction of HBM: L1/L2 serve the repeats).  "
                    "`traffic_frac` = measured L2-miss-side bytes (FETCH_SIZE x 2 + WRITE_SIZE) over the same time"}
     if traffic and avg_ms:
+        out["traffic_bytes_per_launch"] = traffic["fetch_x2"]      # FETCH_SIZE x 2 + WRITE_SIZE of the committed PMC passes
         out["traffic_GBs"] = traffic["fetch_x2"] / 1e9 / (avg_ms * 1e-3)
         out["traffic_frac"] = out["traffic_GBs"] / HBM_PEAK_GBS
     if dom in named_bytes and avg_ms:
