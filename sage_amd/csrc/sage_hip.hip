@@ -88,6 +88,7 @@ struct sage_ctx {
     // embeddings
     DevBuf emb;           // float64 rows (always kept: the exact values)
     DevBuf emb32;         // float32 rows, when most rows are float32-representable (word2vec output is)
+    DevBuf emb_stage, emb_cnt;   // sage_set_embeddings: the caller's contiguous matrix as uploaded; the count of inexact rows
     DevBuf inexact;       // bitmap of the rows that are not: their pairs are recomputed from `emb`
     DevBuf inex_list, inex_count;
     DevBuf w2v_counts, w2v_keep, w2v_dropped, w2v_aprob, w2v_aidx, w2v_syn0, w2v_syn1;   // sage_train_embeddings
@@ -890,7 +891,7 @@ void sage_destroy(sage_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     collect_events(c);
     for (auto e : c->ev_free) (void)hipEventDestroy(e);
-    DevBuf* all[] = {&c->buckets, &c->keys, &c->ebk, &c->parent, &c->parent_old, &c->old_to_new, &c->remap, &c->vk_bytes, &c->vk_off, &c->vk_ids, &c->byte_id, &c->direct2, &c->bloom, &c->pmask, &c->pmask8, &c->corpus, &c->rem, &c->line_off, &c->emb, &c->M, &c->ntok,
+    DevBuf* all[] = {&c->buckets, &c->keys, &c->ebk, &c->parent, &c->parent_old, &c->old_to_new, &c->remap, &c->emb_stage, &c->emb_cnt, &c->vk_bytes, &c->vk_off, &c->vk_ids, &c->byte_id, &c->direct2, &c->bloom, &c->pmask, &c->pmask8, &c->corpus, &c->rem, &c->line_off, &c->emb, &c->M, &c->ntok,
                      &c->tokoff, &c->tile_sums, &c->grand_total, &c->tok_w0, &c->occ_pos, &c->set, &c->seg_line_rel,
                      &c->seg_tok_off, &c->set_base, &c->set_mask, &c->seg_pairs, &c->desc, &c->gcache, &c->bucket_off, &c->rec_a, &c->nocc, &c->occoff, &c->occ_tok,
                      &c->occ_a, &c->exact_list, &c->exact_count, &c->np_ab, &c->dot_off, &c->dots, &c->pool, &c->pool_cursor, &c->np_all, &c->pair_off, &c->seg_first_occ, &c->seg_tile_off,
@@ -1101,40 +1102,35 @@ int sage_set_embeddings(sage_ctx* c, const double* emb, int64_t rows, int32_t di
     if (dim > 512) return fail(c, SAGE_E_LIMIT, "embedding dimension above 512 is not supported");
     HIP_TRY(c, hipSetDevice(c->device));
     const int dp = padded_dim(dim);  // whole 128-byte lines per lane group
+    if (rows >= (1ll << 32)) return fail(c, SAGE_E_LIMIT, "too many embedding rows");
     int rc;
+    const bool want32 = c->score_mode != 1;
+    const size_t bm_words = ((size_t)rows + 31) / 32 + 1;
     if ((rc = ensure(c, c->emb, (size_t)rows * dp * 8))) return rc;
+    if ((rc = ensure(c, c->emb_stage, (size_t)rows * dim * 8))) return rc;
+    if ((rc = ensure(c, c->emb_cnt, 16))) return rc;
+    if (want32) {
+        if ((rc = ensure(c, c->emb32, (size_t)rows * dp * 4))) return rc;
+        if ((rc = ensure(c, c->inexact, bm_words * 4))) return rc;
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (dp != dim) HIP_TRY(c, hipMemset(c->emb.p, 0, (size_t)rows * dp * 8));
-    HIP_TRY(c, hipMemcpy2D(c->emb.p, (size_t)dp * 8, emb, (size_t)dim * 8, (size_t)dim * 8, (size_t)rows, hipMemcpyHostToDevice));
+    // the matrix goes up as it is (one contiguous copy); padding, the float32 copy and the bitmap are made on the device
+    HIP_TRY(c, hipMemcpyAsync(c->emb_stage.p, emb, (size_t)rows * dim * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->emb_cnt.p, 0, 16, c->stream));
+    if (want32) HIP_TRY(c, hipMemsetAsync(c->inexact.p, 0, bm_words * 4, c->stream));
+    k_embed_layout<<<cdiv((uint64_t)rows, 4), 256, 0, c->stream>>>(
+        c->emb_stage.as<double>(), (uint32_t)rows, (uint32_t)dim, (uint32_t)dp, c->emb.as<double>(),
+        want32 ? c->emb32.as<float>() : nullptr, want32 ? c->inexact.as<uint32_t>() : nullptr,
+        c->emb_cnt.as<unsigned long long>());
+    HIP_TRY(c, hipGetLastError());
+    unsigned long long n_inexact = 0;
+    HIP_TRY(c, hipMemcpyAsync(&n_inexact, c->emb_cnt.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->emb_rows = rows;
     c->dim = dim;
     c->dp = dp;
-    // float32 copy + bitmap of the rows it does not represent exactly (embeddings.py:81 fills rows from float32
-    // word2vec vectors, embeddings.py:86 fills the rest from a float64 uniform draw)
-    std::vector<float> e32((size_t)rows * dp, 0.0f);
-    std::vector<uint32_t> bitmap(((size_t)rows + 31) / 32 + 1, 0u);
-    int64_t n_inexact = 0;
-    for (int64_t r = 0; r < rows; ++r) {
-        const double* src = emb + (size_t)r * dim;
-        float* dst = e32.data() + (size_t)r * dp;
-        bool exact = true;
-        for (int d = 0; d < dim; ++d) {
-            dst[d] = (float)src[d];
-            exact = exact && ((double)dst[d] == src[d]);   // false for NaN: such rows keep their float64 form
-        }
-        if (!exact) {
-            bitmap[(size_t)r >> 5] |= 1u << (r & 31); ++n_inexact;
-            for (int d = 0; d < dim; ++d) dst[d] = std::numeric_limits<float>::quiet_NaN();   // marks the row for k_logsig
-        }
-    }
-    c->n_inexact = n_inexact;
-    c->use_f32 = (c->score_mode == 0 && n_inexact * 2 <= rows) || (c->score_mode == 2 && n_inexact < rows);
-    if (c->use_f32) {
-        if ((rc = ensure(c, c->emb32, e32.size() * 4))) return rc;
-        if ((rc = ensure(c, c->inexact, bitmap.size() * 4))) return rc;
-        HIP_TRY(c, hipMemcpy(c->emb32.p, e32.data(), e32.size() * 4, hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(c->inexact.p, bitmap.data(), bitmap.size() * 4, hipMemcpyHostToDevice));
-    }
+    c->n_inexact = (int64_t)n_inexact;
+    c->use_f32 = want32 && ((c->score_mode == 0 && c->n_inexact * 2 <= rows) || (c->score_mode == 2 && c->n_inexact < rows));
     c->have_emb = true;
     return SAGE_OK;
 }

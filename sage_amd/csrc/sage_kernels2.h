@@ -1212,3 +1212,35 @@ __global__ __launch_bounds__(256) void k_logsig(const uint4* __restrict__ desc, 
             else fix_atomic_add(&loss_fix[2 * (size_t)acc_id[i]], &loss_fix[2 * (size_t)acc_id[i] + 1], Fix128{acc_w0[i], (long long)acc_w1[i]});
         }
 }
+
+// ----------------------------------------------------------------------------------------------------------
+// k_embed_layout: the matrix as train_embeddings leaves it (contiguous [rows, dim] float64, uploaded as is) into the
+// device layout: float64 rows padded to whole 128-byte lines, the float32 copy, and the bitmap of the rows the copy
+// cannot hold exactly (embeddings.py:81 fills rows from float32 word2vec vectors, embeddings.py:86 the rest from a
+// float64 uniform draw).  A wave per row; a row with any element that does not survive float64 -> float32 -> float64
+// (NaN included) is marked and its float32 row set to NaN.  (The host did this element by element and uploaded the rows
+// with a pitched copy: 0.96 s per call at 262,144 x 50, six times per README schedule.)
+// ----------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_embed_layout(const double* __restrict__ src, uint32_t rows, uint32_t dim, uint32_t dp,
+                                                      double* __restrict__ emb, float* __restrict__ e32 /* or nullptr */,
+                                                      uint32_t* __restrict__ bitmap /* zeroed */,
+                                                      unsigned long long* __restrict__ n_inexact /* zeroed */) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t r = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    bool exact = true;
+    for (uint32_t d = lane; d < dp; d += 64u) {
+        const double v = d < dim ? src[(size_t)r * dim + d] : 0.0;
+        emb[(size_t)r * dp + d] = v;
+        exact = exact && (double)(float)v == v;        // false for NaN: such rows keep their float64 form
+    }
+    const bool row_exact = __ballot(!exact) == 0ull;
+    if (lane == 0u && !row_exact) atomicAdd(n_inexact, 1ull);
+    if (e32 == nullptr) return;                        // float64-only storage: the count alone
+    const float qnan = __builtin_nanf("");
+    for (uint32_t d = lane; d < dp; d += 64u) {
+        const float f = d < dim ? (float)src[(size_t)r * dim + d] : 0.0f;
+        e32[(size_t)r * dp + d] = (row_exact || d >= dim) ? f : qnan;      // a marked row is NaN in the copy (padding stays 0)
+    }
+    if (lane == 0u && !row_exact) atomicOr(&bitmap[r >> 5], 1u << (r & 31u));
+}
