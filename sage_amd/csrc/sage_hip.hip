@@ -18,6 +18,7 @@
 #include "sage_kernels.h"
 #include "sage_kernels2.h"
 #include "sage_kernels3.h"
+#include "sage_kernels4.h"
 #include "sage_w2v.h"
 
 #define SAGE_VERSION_STR "0.1.0"
@@ -96,6 +97,7 @@ struct sage_ctx {
     int64_t emb_rows = 0, n_inexact = 0;
     int dim = 0, dp = 0;
     bool have_emb = false;
+    bool dots2 = true;     // k_dots2 (sage_kernels4.h) for the score kernel; SAGE_DOTS2=0 selects k_dots
     bool use_f32 = false;
     int score_mode = 0;   // 0 = float32 storage when lossless for most rows, 1 = always float64 storage
 
@@ -369,9 +371,33 @@ void launch_pairs(sage_ctx* c, const T* emb, const uint32_t* tok_w0, uint32_t n_
                                                                     c->gcache.as<double2>(), c->flags.as<uint32_t>(), nullptr);
 }
 
+#ifndef DOTS2_P
+#define DOTS2_P 6
+#endif
+// k_dots2 (sage_kernels4.h) addresses rows by 32-bit byte offsets: matrices under 4 GiB (every configuration of the survey)
+template <int G, int EPL, typename T, bool LIST>
+void launch_dots2(sage_ctx* c, const T* emb, uint32_t n_occ, const uint32_t* list, const uint32_t* list_count) {
+    static std::atomic<int> cached{0};
+    int per_cu = cached.load(std::memory_order_relaxed);
+    if (per_cu == 0) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_dots2<G, EPL, T, DOTS2_P, LIST>, 256, 0) != hipSuccess || per_cu < 1)
+            per_cu = 4;
+        cached.store(per_cu, std::memory_order_relaxed);
+    }
+    const uint32_t grid = std::min<uint32_t>(cdiv(n_occ, 256 / G), (uint32_t)c->n_cu * (uint32_t)std::max(per_cu, 1));
+    k_dots2<G, EPL, T, DOTS2_P, LIST><<<grid, 256, 0, c->stream>>>(
+        c->desc.as<uint4>(), c->pool.as<uint32_t>(), n_occ, c->dot_off.as<uint32_t>(), emb, (uint32_t)c->emb_rows,
+        (uint32_t)c->dp, c->dots.as<double>(), c->flags.as<uint32_t>(), list, list_count);
+}
+
 template <int G, int EPL, typename T, int NS = 5>
 void launch_dots(sage_ctx* c, const T* emb, uint32_t n_occ, const uint32_t* list, const uint32_t* list_count, int cls) {
     Prof p(c, cls);
+    if (c->dots2 && (uint64_t)c->emb_rows * (uint64_t)c->dp * sizeof(T) < (1ull << 32) && c->emb_rows < (1ll << 24)) {
+        if (list) launch_dots2<G, EPL, T, true>(c, emb, n_occ, list, list_count);
+        else launch_dots2<G, EPL, T, false>(c, emb, n_occ, nullptr, nullptr);
+        return;
+    }
     // persistent: exactly as many workgroups as the chip holds at once (a partial second round would double the time)
     static std::atomic<int> cached{0};   // per instantiation; the same for every gfx950 device
     int per_cu = cached.load(std::memory_order_relaxed);
@@ -876,6 +902,7 @@ int sage_create(int device, sage_ctx** out_ctx) {
         (void)hipStreamDestroy(c->stream); delete c; return SAGE_E_HIP;
     }
     if (const char* e = std::getenv("SAGE_DEBUG_PART")) c->debug_part = std::atoi(e) != 0;
+    if (const char* e = std::getenv("SAGE_DOTS2")) c->dots2 = std::atoi(e) != 0;
     if (const char* e = std::getenv("SAGE_M_RESIDENT_MAX_GB")) { const long long x = std::atoll(e); if (x >= 0) c->m_resident_max = (int64_t)x << 30; }
     if (const char* e = std::getenv("SAGE_TEST_PAIR_LIMIT")) { const long long x = std::atoll(e); if (x > 0) c->pair_limit = (uint64_t)x; }
     if (hipMalloc(&c->flags.p, FLAG_COUNT * 4) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return SAGE_E_HIP; }
