@@ -412,9 +412,29 @@ void launch_dots(sage_ctx* c, const T* emb, uint32_t n_occ, const uint32_t* list
         (uint32_t)c->dp, c->dots.as<double>(), c->flags.as<uint32_t>(), list, list_count);
 }
 // the float64 pass over the inexact list with float32 rows where the copy holds them (k_dots<..., MIXED>)
+#ifndef DOTS2_MIXED_P
+#define DOTS2_MIXED_P 6
+#endif
 template <int G, int EPL>
 void launch_dots_mixed(sage_ctx* c, uint32_t n_occ) {
     Prof p(c, SAGE_K_FIX);
+    if constexpr (EPL % 4 == 0) {
+        if (c->dots2 && (uint64_t)c->emb_rows * (uint64_t)c->dp * 8u < (1ull << 32) && c->emb_rows < (1ll << 24)) {
+            static std::atomic<int> cached2{0};
+            int per_cu = cached2.load(std::memory_order_relaxed);
+            if (per_cu == 0) {
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_dots2_mixed<G, EPL, DOTS2_MIXED_P>, 256, 0) != hipSuccess || per_cu < 1)
+                    per_cu = 3;
+                cached2.store(per_cu, std::memory_order_relaxed);
+            }
+            const uint32_t grid = std::min<uint32_t>(cdiv(n_occ, 256 / G), (uint32_t)c->n_cu * (uint32_t)std::max(per_cu, 1));
+            k_dots2_mixed<G, EPL, DOTS2_MIXED_P><<<grid, 256, 0, c->stream>>>(
+                c->desc.as<uint4>(), c->pool.as<uint32_t>(), n_occ, c->dot_off.as<uint32_t>(), c->emb.as<double>(), (uint32_t)c->emb_rows,
+                (uint32_t)c->dp, c->dots.as<double>(), c->flags.as<uint32_t>(), c->inex_list.as<uint32_t>(), c->inex_count.as<uint32_t>(),
+                c->emb32.as<float>(), c->inexact.as<uint32_t>(), c->stats.as<unsigned long long>());
+            return;
+        }
+    }
     static std::atomic<int> cached{0};
     int per_cu = cached.load(std::memory_order_relaxed);
     if (per_cu == 0) {

@@ -61,16 +61,27 @@ __device__ __forceinline__ void group_dot_pair(const double (&a)[EPL], const dou
     d1 = x; d2 = y;
 }
 
-template <int G, int EPL, typename T, int P, bool LIST>
-__global__ __launch_bounds__(256) void k_dots2(const uint4* __restrict__ desc, const uint32_t* __restrict__ pool,
-                                               uint32_t n_occ, const uint32_t* __restrict__ dot_off,
-                                               const T* emb /* not __restrict__: see the row loads */, uint32_t emb_rows, uint32_t dp,
-                                               double* dots, uint32_t* __restrict__ flags,
-                                               const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count) {
+// MIXED (T = double, the pass over the inexact list): a row marked in `bitmap` comes from the float64 matrix, any other
+// from the float32 copy -- half the bytes -- as in k_dots_mixed.  Here the choice costs no branch: a lane owns EPL
+// CONSECUTIVE elements of a row (32 bytes of a float32 row, 64 of a float64 row, at twice the offset), every step issues
+// the same 16-byte loads from a per-lane base (the second half of a float32 slice re-reads the first: a cache hit), and the
+// widening picks per lane between "convert the first EPL words" and "the words are the doubles".  The mark of an element
+// is looked up one period after its id has arrived (one more batch in flight: Eq).
+template <int G, int EPL, typename T, int P, bool LIST, bool MIXED>
+__device__ __forceinline__ void dots2_body(const uint4* __restrict__ desc, const uint32_t* __restrict__ pool,
+                                           uint32_t n_occ, const uint32_t* __restrict__ dot_off,
+                                           const T* emb /* not __restrict__: see the row loads */, uint32_t emb_rows, uint32_t dp,
+                                           double* dots, uint32_t* __restrict__ flags,
+                                           const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count,
+                                           const float* emb32, const uint32_t* __restrict__ bitmap,
+                                           unsigned long long* __restrict__ stats) {
     static_assert(G >= 8 && P >= 4 && P <= 8, "a group plans P <= 8 elements and keeps 8 occurrences, one per lane");
+    static_assert(!MIXED || (std::is_same<T, double>::value && EPL % 4 == 0), "MIXED: float64 kernel, slices of whole 16-byte loads");
     constexpr int NF = P - 3;              // rows in flight in front of the current one and its two predecessors
     constexpr int K = 1 + P / 2;           // occurrences a period of P elements can touch (windows have >= 2 ids)
-    constexpr bool WIDEN = !std::is_same<T, double>::value;
+    constexpr bool WIDEN = MIXED || !std::is_same<T, double>::value;
+    constexpr int NW = MIXED ? 2 * EPL : 1;      // MIXED: words of a raw slice (a float64 slice; a float32 slice fills half)
+    constexpr uint32_t IDLE_END = MIXED ? 4u : 3u;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t gl = threadIdx.x % G;
     const uint32_t n = LIST ? *list_count : n_occ;
@@ -100,14 +111,26 @@ __global__ __launch_bounds__(256) void k_dots2(const uint4* __restrict__ desc, c
     // element batches: period r (E0), period r+1 (E1), planned with the id in flight (Ep); word = id | flags << 24
     // (bit24: dot with the previous element, bit25: with the one before, bit26: element exists), dst = where its dots go
     uint32_t E0 = 0, E0_dst = 0, E1 = 0, E1_dst = 0, Ep_id = 0, Ep_fl = 0, Ep_dst = 0;
-    uint32_t oob = 0, wn = 0;
+    uint32_t Eq = 0, Eq_dst = 0, Eq_bw = 0;      // MIXED: the batch between Ep and E1 (ids there, bitmap words in flight)
+    uint32_t oob = 0, wn = 0, n_marked = 0;
     double k1 = 0.0, k2 = 0.0;
-    T B[P][EPL];
+    T B[MIXED ? 1 : P][EPL];
+    uint32_t R[MIXED ? P : 1][NW], Mk[MIXED ? P : 1];
     double C[WIDEN ? P : 1][EPL];
 #pragma unroll
-    for (int s = 0; s < P; ++s)
+    for (int s = 0; s < (MIXED ? 1 : P); ++s)
 #pragma unroll
         for (int e = 0; e < EPL; ++e) B[s][e] = (T)0;
+#pragma unroll
+    for (int s = 0; s < (MIXED ? P : 1); ++s) {
+        Mk[s] = 0;
+#pragma unroll
+        for (int e = 0; e < NW; ++e) R[s][e] = 0;
+    }
+#pragma unroll
+    for (int s = 0; s < (WIDEN ? P : 1); ++s)
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) C[s][e] = 0.0;
 
     for (;;) {
         // (1) the dots of the period that has just run leave: lane t holds those of its element t
@@ -118,8 +141,18 @@ __global__ __launch_bounds__(256) void k_dots2(const uint4* __restrict__ desc, c
         {
             uint32_t id = Ep_id;
             if (id >= emb_rows) { oob |= (Ep_fl >> 2) & 1u; id = 0u; }
-            E1 = id | (Ep_fl << 24);
-            E1_dst = Ep_dst;
+            if constexpr (MIXED) {
+                const uint32_t marked = (Eq_bw >> (Eq & 31u)) & 1u;          // (bit 27 of the word: the row is a float64 row)
+                n_marked += marked & (Eq >> 26);
+                E1 = Eq | (marked << 27);
+                E1_dst = Eq_dst;
+                Eq = id | (Ep_fl << 24);
+                Eq_dst = Ep_dst;
+                Eq_bw = bitmap[id >> 5];
+            } else {
+                E1 = id | (Ep_fl << 24);
+                E1_dst = Ep_dst;
+            }
         }
         // (4) stage B has landed: into the ring
         {
@@ -216,13 +249,26 @@ __global__ __launch_bounds__(256) void k_dots2(const uint4* __restrict__ desc, c
                 // the word of the element whose row takes off now was asked for a step ago (below); the wait is written
                 // here because the compiler does not know of the instruction
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wn));
-                const uint32_t off = __umul24(wn, row_bytes) + slice;     // (the low 24 bits of the word: the id)
-#if defined(DOTS_ABL) && (DOTS_ABL == 2 || DOTS_ABL == 5)     // timing ablation: no row loads
+                if constexpr (MIXED) {
+                    const uint32_t m = (wn >> 27) & 1u;
+                    Mk[tn] = m;
+                    const uint32_t off = (__umul24(wn, dp * 4u) + gl * (uint32_t)(EPL * 4)) << m;    // the float64 row and slice: twice the offset
+                    const char* a0 = (m ? ebase : reinterpret_cast<const char*>(emb32)) + off;
+                    const char* a1 = a0 + (m ? (uint32_t)(EPL * 4) : 0u);
 #pragma unroll
-                for (int e = 0; e < EPL; ++e) B[tn][e] = (T)(off + e);
-#else
-                load_row_at<G, EPL, T>(ebase, off, B[tn]);
-#endif
+                    for (int i = 0; i < EPL / 4; ++i) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(a0 + 16 * i);
+                        R[tn][4 * i] = v.x; R[tn][4 * i + 1] = v.y; R[tn][4 * i + 2] = v.z; R[tn][4 * i + 3] = v.w;
+                    }
+#pragma unroll
+                    for (int i = 0; i < EPL / 4; ++i) {
+                        const uint4 v = *reinterpret_cast<const uint4*>(a1 + 16 * i);
+                        R[tn][EPL + 4 * i] = v.x; R[tn][EPL + 4 * i + 1] = v.y; R[tn][EPL + 4 * i + 2] = v.z; R[tn][EPL + 4 * i + 3] = v.w;
+                    }
+                } else {
+                    const uint32_t off = __umul24(wn, row_bytes) + slice;     // (the low 24 bits of the word: the id)
+                    load_row_at<G, EPL, T>(ebase, off, B[tn]);
+                }
             }
             // (straight-line code: without a compiler-level memory barrier the instruction selector's own ordering sinks
             // each row load to just above its first use, NF steps later, to save registers -- and the gather latency is
@@ -242,32 +288,59 @@ __global__ __launch_bounds__(256) void k_dots2(const uint4* __restrict__ desc, c
             // the current row passes through an (empty) asm statement: asm statements keep their order, so the arithmetic of
             // step t, which hangs on this one, stays below the load issue of step t (pinned by the barrier above) -- otherwise
             // the steps of a period, one basic block, are interleaved at will and rows are consumed right after their loads
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) asm volatile("" : "+v"(B[t][e]));
             double d1, d2;
-            if constexpr (WIDEN) {
+            if constexpr (MIXED) {
 #pragma unroll
-#if defined(DOTS_ABL) && DOTS_ABL == 3     // timing ablation: no conversions
-                for (int e = 0; e < EPL; ++e) C[t][e] = __hiloint2double(0x3ff00000, __float_as_int(B[t][e]));
-#else
-                for (int e = 0; e < EPL; ++e) C[t][e] = (double)B[t][e];
-#endif
-#if defined(DOTS_ABL) && (DOTS_ABL == 4 || DOTS_ABL == 5)    // timing ablation: no arithmetic
-                d1 = C[t][0] + C[tp][1]; d2 = C[t][2] + C[tpp][3];
-#else
+                for (int e = 0; e < NW; ++e) asm volatile("" : "+v"(R[t][e]));
+                const bool m = Mk[t] != 0u;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) {
+                    const double from32 = (double)__uint_as_float(R[t][e]);
+                    const double from64 = __hiloint2double((int)R[t][2 * e + 1], (int)R[t][2 * e]);
+                    C[t][e] = m ? from64 : from32;
+                }
                 group_dot_pair<G, EPL>(C[t], C[tp], C[tpp], d1, d2);
-#endif
+            } else if constexpr (WIDEN) {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) asm volatile("" : "+v"(B[t][e]));
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) C[t][e] = (double)B[t][e];
+                group_dot_pair<G, EPL>(C[t], C[tp], C[tpp], d1, d2);
             } else {
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) asm volatile("" : "+v"(B[t][e]));
                 group_dot_pair<G, EPL>(B[t], B[tp], B[tpp], d1, d2);
             }
             k1 = gl == (uint32_t)t ? d1 : k1;
             k2 = gl == (uint32_t)t ? d2 : k2;
             __builtin_amdgcn_sched_barrier(0);
         }
-        // (8) three periods with nothing planned for any group of the wave: everything planned has run and its dots have
+        // (8) three periods (MIXED: four) with nothing planned for any group of the wave: everything planned has run and its dots have
         // left at (1).  (Tested HERE, after the steps, so that the loop has one way round: with a way past the steps the
         // counted waits of the next pass are computed for that way -- hardly any loads in flight -- and drain the rows.)
-        if (__all(idle >= 3u)) break;
+        if (__all(idle >= IDLE_END)) break;
     }
     if (oob) flags[FLAG_ROW_OOB] = 1;
+    if constexpr (MIXED) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) n_marked += __shfl_down(n_marked, d, 64);
+        if ((threadIdx.x & 63u) == 0u && n_marked && stats) atomicAdd(&stats[STAT_MARKED_ROWS], (unsigned long long)n_marked);
+    }
+}
+
+template <int G, int EPL, typename T, int P, bool LIST>
+__global__ __launch_bounds__(256) void k_dots2(const uint4* __restrict__ desc, const uint32_t* __restrict__ pool,
+                                               uint32_t n_occ, const uint32_t* __restrict__ dot_off,
+                                               const T* emb, uint32_t emb_rows, uint32_t dp, double* dots, uint32_t* __restrict__ flags,
+                                               const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_count) {
+    dots2_body<G, EPL, T, P, LIST, false>(desc, pool, n_occ, dot_off, emb, emb_rows, dp, dots, flags, list, list_count, nullptr, nullptr, nullptr);
+}
+template <int G, int EPL, int P>
+__global__ __launch_bounds__(256) void k_dots2_mixed(const uint4* __restrict__ desc, const uint32_t* __restrict__ pool,
+                                                     uint32_t n_occ, const uint32_t* __restrict__ dot_off,
+                                                     const double* emb, uint32_t emb_rows, uint32_t dp, double* dots,
+                                                     uint32_t* __restrict__ flags, const uint32_t* __restrict__ list,
+                                                     const uint32_t* __restrict__ list_count, const float* emb32,
+                                                     const uint32_t* __restrict__ bitmap, unsigned long long* __restrict__ stats) {
+    dots2_body<G, EPL, double, P, true, true>(desc, pool, n_occ, dot_off, emb, emb_rows, dp, dots, flags, list, list_count, emb32, bitmap, stats);
 }
