@@ -671,9 +671,6 @@ __global__ __launch_bounds__(256) void k_pair_cache(const uint32_t* __restrict__
 // matrix; the other rows of such a window (all but one of its ~7, on average) come from the float32 copy `emb32` --
 // half the bytes -- and are widened when they become current.  The bitmap word of an id is fetched one step before
 // its row load is issued, so the choice costs no exposed latency (one more id in flight than the plain kernel).
-#ifndef DOTS_ABL
-#define DOTS_ABL 0
-#endif
 template <int G, int EPL, typename T, int NS, bool MIXED = false>
 __device__ __forceinline__ void dots_body(const uint4* __restrict__ desc, const uint32_t* __restrict__ pool,
                                               uint32_t n_occ, const uint32_t* __restrict__ dot_off,
@@ -843,12 +840,7 @@ __device__ __forceinline__ void dots_body(const uint4* __restrict__ desc, const 
                     n_marked += (rlive && gl == 0u) ? 1u : 0u;
                 }
             } else {
-#if DOTS_ABL == 2
-#pragma unroll
-                for (int e = 0; e < EPL; ++e) B[(s + NF) % NS][e] = (T)(rid + e);
-#else
                 load_row_slice<G, EPL>(emb, rid, dp, gl, B[(s + NF) % NS]);
-#endif
             }
             if constexpr (MIXED) { if (m0 & 16u) widen_slice<EPL>(B[s]); }
             if constexpr (WIDEN) {
@@ -862,23 +854,15 @@ __device__ __forceinline__ void dots_body(const uint4* __restrict__ desc, const 
                 }
                 if (m0 & 1u) {
                     double d_;
-#if DOTS_ABL == 1
-                    if constexpr (WIDEN) d_ = C[s][0] + C[(s + NS - 1) % NS][0]; else d_ = B[s][0] + B[(s + NS - 1) % NS][0];
-#else
                     if constexpr (WIDEN) d_ = group_dot<G, EPL, double>(C[s], C[(s + NS - 1) % NS]);
                     else d_ = group_dot<G, EPL, T>(B[s], B[(s + NS - 1) % NS]);
-#endif
                     if (gl == pend) mydot = d_;
                     if (++pend == 8u) { if (gl < 8u) dots[wr + gl] = mydot; wr += 8u; pend = 0; }
                 }
                 if (m0 & 2u) {
                     double d_;
-#if DOTS_ABL == 1
-                    if constexpr (WIDEN) d_ = C[s][0] + C[(s + NS - 2) % NS][0]; else d_ = B[s][0] + B[(s + NS - 2) % NS][0];
-#else
                     if constexpr (WIDEN) d_ = group_dot<G, EPL, double>(C[s], C[(s + NS - 2) % NS]);
                     else d_ = group_dot<G, EPL, T>(B[s], B[(s + NS - 2) % NS]);
-#endif
                     if (gl == pend) mydot = d_;
                     if (++pend == 8u) { if (gl < 8u) dots[wr + gl] = mydot; wr += 8u; pend = 0; }
                 }

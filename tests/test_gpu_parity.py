@@ -591,3 +591,47 @@ def test_oracle_at_twenty_thousand_lines():
     tt, ttr, losses, sizes = orc.run_parallel(emb, lines, tok, W, processes=W)
     _check_step(eng, segment_line_bounds(n_lines, W), tt, ttr, losses, sizes)
     eng.close()
+
+
+@pytest.mark.parametrize("score_mode", [0, 1])
+def test_score_kernels_agree_on_short_windows(score_mode, monkeypatch):
+    """600,000 one- and two-word lines: windows of two or three elements, far more occurrences than the score kernel has
+    groups, so a group of k_dots2 (sage_kernels4.h) uses up its ring of 8 upcoming occurrences faster than the two-stage
+    top-up refills it and runs periods with unfilled elements between occurrences.  Checked against k_dots / k_dots_mixed
+    (SAGE_DOTS2=0: another kernel, per-element bookkeeping) in deterministic mode: counts equal, losses equal to 1e-12
+    relative (the float32 and float64 kernels sum every dot in the same order in both; the mixed-storage kernel owns other
+    elements per lane).  The oracle covers the same shapes at small size (test_tiny_lines_vs_oracle)."""
+    from sage_amd import synth
+    from sage_amd.parallel import segment_line_bounds
+    base, boff = synth.make_corpus(4000, seed=77, style="en", n_types=30_000)
+    vocab = synth.make_vocab(base, boff, 8192, 12, sample_bytes=1_000_000)
+    words = np.array([w for ln in synth.corpus_lines(base, boff) for w in ln.split()], dtype=object)
+    rs = np.random.RandomState(11)
+    pick = words[rs.randint(0, len(words), size=1_200_001)]
+    two = rs.rand(600_000) < 0.5
+    lines, at = [], 0
+    for t in two:
+        lines.append(pick[at] + " " + pick[at + 1] if t and at + 1 < len(pick) else pick[at])
+        at += 2 if t else 1
+    corpus, off = _pack(lines)
+    res = []
+    for dots2 in ("0", "1"):
+        monkeypatch.setenv("SAGE_DOTS2", dots2)
+        eng = _engine()
+        eng.set_score_mode(score_mode)
+        eng.set_deterministic(True)
+        eng.set_vocab(vocab, None, 12)
+        eng.set_corpus(corpus, off)
+        counts = np.bincount(eng.tokenize(0, len(lines))[0], minlength=len(vocab))
+        emb = synth.make_embeddings(len(vocab), 50, seed=3, unseen=~(counts > 0))
+        eng.set_embeddings(emb)
+        res.append(eng.ablation_step(segment_line_bounds(len(lines), 4)))
+        eng.close()
+    (l0, o0, t0, r0, h0), (l1, o1, t1, r1, h1) = res
+    assert (t0, r0) == (t1, r1) and t0 > 600_000
+    np.testing.assert_array_equal(o0, o1)
+    np.testing.assert_array_equal(h0, h1)
+    scale = np.abs(l0).max()
+    np.testing.assert_allclose(l1, l0, rtol=1e-12, atol=1e-12 * scale)
+    if score_mode == 1:
+        np.testing.assert_array_equal(l1, l0)      # one kernel pair, the same sums: bit for bit
