@@ -38,10 +38,10 @@ sys.path.insert(0, str(REPO))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # kernel class (sage_hip.h SAGE_K_*) -> the kernel that dominates it in the rocprofv3 traces under profiles/
-CLASS_KERNEL = {"match": "k_match_lds", "score": "k_dots", "count": "k_key_dedupe", "partition": "k_key_partition3",
+CLASS_KERNEL = {"match": "k_match_lds", "score": "k_dots2<", "fix": "k_dots2_mixed", "count": "k_key_dedupe", "partition": "k_key_partition3",
                 "describe": "k_describe<false>", "pairs": "k_pair_cache", "logsig": "k_logsig", "walk": "k_walk_write"}
 # what bounds each kernel class (Kernels): only the "hbm" ones stream HBM; the HBM peak is quoted for all
-CLASS_BOUND = {"match": "l2-miss-traffic", "score": "row-gather-latency", "pairs": "l2-fabric-gather", "fix": "row-gather-latency",
+CLASS_BOUND = {"match": "l2-miss-traffic", "score": "l2-fabric-gather", "pairs": "l2-fabric-gather", "fix": "l2-fabric-gather",
                "count": "hbm", "partition": "hbm", "describe": "lds-latency", "logsig": "hbm", "walk": "latency"}
 
 

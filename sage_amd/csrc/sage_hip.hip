@@ -97,6 +97,7 @@ struct sage_ctx {
     int64_t emb_rows = 0, n_inexact = 0;
     int dim = 0, dp = 0;
     bool have_emb = false;
+    double f64_switch = -1.0;   // share of occurrences on the float64 pass above which later steps use the float64 matrix alone (SAGE_F64_SWITCH; < 0: by kernel)
     bool dots2 = true;     // k_dots2 (sage_kernels4.h) for the score kernel; SAGE_DOTS2=0 selects k_dots
     bool use_f32 = false;
     int score_mode = 0;   // 0 = float32 storage when lossless for most rows, 1 = always float64 storage
@@ -886,9 +887,12 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
         c->step_stats[14] = (c->count_mode == 1 || c->count_fallback) ? 1 : 0;   // which back end produced total_triples
         c->step_stats[15] = (c->exact_buckets ? 1 : 0) | (ran_without_matcher ? 2 : 0);
         // The share of ROWS that float32 cannot hold says little about the share of OCCURRENCES that touch one; the
-        // step just measured the latter.  Above 30 % the float64 pass costs more than the float32 copy saves: later
-        // steps (until the next sage_set_embeddings) use the float64 matrix alone.  Results do not depend on this.
-        if (c->use_f32 && c->score_mode == 0 && (double)stats[STAT_INEXACT] > 0.30 * (double)total_occ) c->use_f32 = false;
+        // step just measured the latter.  With k_dots_mixed (D = 300 here, or SAGE_DOTS2=0) the float64 pass costs more
+        // than the float32 copy saves above 30 %: later steps (until the next sage_set_embeddings) then use the float64
+        // matrix alone.  With k_dots2_mixed the split wins at every share (79 % on the float64 pass: 9.2 ms per 300k lines
+        // against 10.5 for the float64 matrix alone), so there is no switch.  Results do not depend on this.
+        const double thr = c->f64_switch >= 0.0 ? c->f64_switch : ((c->dots2 && c->dp != 384) ? 2.0 : 0.30);
+        if (c->use_f32 && c->score_mode == 0 && (double)stats[STAT_INEXACT] > thr * (double)total_occ) c->use_f32 = false;
         return SAGE_OK;
     }
 }
@@ -923,6 +927,7 @@ int sage_create(int device, sage_ctx** out_ctx) {
     }
     if (const char* e = std::getenv("SAGE_DEBUG_PART")) c->debug_part = std::atoi(e) != 0;
     if (const char* e = std::getenv("SAGE_DOTS2")) c->dots2 = std::atoi(e) != 0;
+    if (const char* e = std::getenv("SAGE_F64_SWITCH")) { const double x = std::atof(e); if (x >= 0.0) c->f64_switch = x; }
     if (const char* e = std::getenv("SAGE_M_RESIDENT_MAX_GB")) { const long long x = std::atoll(e); if (x >= 0) c->m_resident_max = (int64_t)x << 30; }
     if (const char* e = std::getenv("SAGE_TEST_PAIR_LIMIT")) { const long long x = std::atoll(e); if (x > 0) c->pair_limit = (uint64_t)x; }
     if (hipMalloc(&c->flags.p, FLAG_COUNT * 4) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return SAGE_E_HIP; }

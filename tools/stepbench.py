@@ -15,7 +15,11 @@ else:
     corpus, off = synth.make_corpus(N, seed=seed, line_seed=int(os.environ.get("SB_LINE_SEED", "0")), style="en", n_types=1_000_000)
 e = HipSage(0); e.set_vocab(vocab, None, 16); e.set_corpus(corpus, off)
 counts = np.bincount(e.tokenize(0, N)[0], minlength=len(vocab))
-emb = synth.make_embeddings(len(vocab), int(os.environ.get('SB_DIM', '50')), seed=seed, unseen=~(counts > 0))
+unseen = ~(counts > 0)
+if os.environ.get('SB_STALE'):      # float64 rows where the corpus does use them, as between two retrain labels (ids moved, rows did not)
+    unseen = np.random.RandomState(1).rand(len(vocab)) < float(os.environ['SB_STALE'])
+emb = synth.make_embeddings(len(vocab), int(os.environ.get('SB_DIM', '50')), seed=seed, unseen=unseen)
+if os.environ.get('SB_SCORE_MODE'): e.set_score_mode(int(os.environ['SB_SCORE_MODE']))
 e.set_embeddings(emb)
 b = segment_line_bounds(N, 4)
 for _ in range(3): r = e.ablation_step(b)     # warm-up: the first steps on a fresh box run at ramping clocks
