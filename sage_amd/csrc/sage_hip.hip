@@ -378,15 +378,18 @@ void launch_pairs(sage_ctx* c, const T* emb, const uint32_t* tok_w0, uint32_t n_
 // k_dots2 (sage_kernels4.h) addresses rows by 32-bit byte offsets: matrices under 4 GiB (every configuration of the survey)
 template <int G, int EPL, typename T, bool LIST>
 void launch_dots2(sage_ctx* c, const T* emb, uint32_t n_occ, const uint32_t* list, const uint32_t* list_count) {
+    // period: 6 elements (3 rows in flight); slices of 12 floats (D = 300) run better with 5 (21.2 against 22.9 ms per 300k
+    // lines, 159 registers at 6; k_dots: 22.0)
+    constexpr int P2 = EPL > 8 ? 5 : DOTS2_P;
     static std::atomic<int> cached{0};
     int per_cu = cached.load(std::memory_order_relaxed);
     if (per_cu == 0) {
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_dots2<G, EPL, T, DOTS2_P, LIST>, 256, 0) != hipSuccess || per_cu < 1)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_dots2<G, EPL, T, P2, LIST>, 256, 0) != hipSuccess || per_cu < 1)
             per_cu = 4;
         cached.store(per_cu, std::memory_order_relaxed);
     }
     const uint32_t grid = std::min<uint32_t>(cdiv(n_occ, 256 / G), (uint32_t)c->n_cu * (uint32_t)std::max(per_cu, 1));
-    k_dots2<G, EPL, T, DOTS2_P, LIST><<<grid, 256, 0, c->stream>>>(
+    k_dots2<G, EPL, T, P2, LIST><<<grid, 256, 0, c->stream>>>(
         c->desc.as<uint4>(), c->pool.as<uint32_t>(), n_occ, c->dot_off.as<uint32_t>(), emb, (uint32_t)c->emb_rows,
         (uint32_t)c->dp, c->dots.as<double>(), c->flags.as<uint32_t>(), list, list_count);
 }
@@ -419,17 +422,20 @@ void launch_dots(sage_ctx* c, const T* emb, uint32_t n_occ, const uint32_t* list
 template <int G, int EPL>
 void launch_dots_mixed(sage_ctx* c, uint32_t n_occ) {
     Prof p(c, SAGE_K_FIX);
-    if constexpr (EPL % 4 == 0) {
+    // (rows of 384 elements: the float64 kernels use 64 lanes x 6 doubles, k_dots2_mixed 32 lanes x 12 -- whole 16-byte
+    // loads of a float32 slice)
+    constexpr int G2 = (G == 64 && EPL == 6) ? 32 : G, EPL2 = (G == 64 && EPL == 6) ? 12 : EPL;
+    if constexpr (EPL2 % 4 == 0) {
         if (c->dots2 && (uint64_t)c->emb_rows * (uint64_t)c->dp * 8u < (1ull << 32) && c->emb_rows < (1ll << 24)) {
             static std::atomic<int> cached2{0};
             int per_cu = cached2.load(std::memory_order_relaxed);
             if (per_cu == 0) {
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_dots2_mixed<G, EPL, DOTS2_MIXED_P>, 256, 0) != hipSuccess || per_cu < 1)
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_dots2_mixed<G2, EPL2, DOTS2_MIXED_P>, 256, 0) != hipSuccess || per_cu < 1)
                     per_cu = 3;
                 cached2.store(per_cu, std::memory_order_relaxed);
             }
-            const uint32_t grid = std::min<uint32_t>(cdiv(n_occ, 256 / G), (uint32_t)c->n_cu * (uint32_t)std::max(per_cu, 1));
-            k_dots2_mixed<G, EPL, DOTS2_MIXED_P><<<grid, 256, 0, c->stream>>>(
+            const uint32_t grid = std::min<uint32_t>(cdiv(n_occ, 256 / G2), (uint32_t)c->n_cu * (uint32_t)std::max(per_cu, 1));
+            k_dots2_mixed<G2, EPL2, DOTS2_MIXED_P><<<grid, 256, 0, c->stream>>>(
                 c->desc.as<uint4>(), c->pool.as<uint32_t>(), n_occ, c->dot_off.as<uint32_t>(), c->emb.as<double>(), (uint32_t)c->emb_rows,
                 (uint32_t)c->dp, c->dots.as<double>(), c->flags.as<uint32_t>(), c->inex_list.as<uint32_t>(), c->inex_count.as<uint32_t>(),
                 c->emb32.as<float>(), c->inexact.as<uint32_t>(), c->stats.as<unsigned long long>());
@@ -887,11 +893,13 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
         c->step_stats[14] = (c->count_mode == 1 || c->count_fallback) ? 1 : 0;   // which back end produced total_triples
         c->step_stats[15] = (c->exact_buckets ? 1 : 0) | (ran_without_matcher ? 2 : 0);
         // The share of ROWS that float32 cannot hold says little about the share of OCCURRENCES that touch one; the
-        // step just measured the latter.  With k_dots_mixed (D = 300 here, or SAGE_DOTS2=0) the float64 pass costs more
-        // than the float32 copy saves above 30 %: later steps (until the next sage_set_embeddings) then use the float64
-        // matrix alone.  With k_dots2_mixed the split wins at every share (79 % on the float64 pass: 9.2 ms per 300k lines
-        // against 10.5 for the float64 matrix alone), so there is no switch.  Results do not depend on this.
-        const double thr = c->f64_switch >= 0.0 ? c->f64_switch : ((c->dots2 && c->dp != 384) ? 2.0 : 0.30);
+        // step just measured the latter.  With k_dots_mixed (matrices of 4 GiB and more, or SAGE_DOTS2=0) the float64 pass
+        // costs more than the float32 copy saves above 30 %: later steps (until the next sage_set_embeddings) then use the
+        // float64 matrix alone.  With k_dots2_mixed the split wins at every share (79 % on the float64 pass: 9.2 ms per
+        // 300k lines against 10.5 for the float64 matrix alone at D = 50, 50.6 against 65.6 at D = 300), so there is no
+        // switch.  Results do not depend on this.
+        const bool mixed2 = c->dots2 && (uint64_t)c->emb_rows * (uint64_t)c->dp * 8u < (1ull << 32) && c->emb_rows < (1ll << 24);
+        const double thr = c->f64_switch >= 0.0 ? c->f64_switch : (mixed2 ? 2.0 : 0.30);
         if (c->use_f32 && c->score_mode == 0 && (double)stats[STAT_INEXACT] > thr * (double)total_occ) c->use_f32 = false;
         return SAGE_OK;
     }
