@@ -98,6 +98,7 @@ struct sage_ctx {
     int dim = 0, dp = 0;
     bool have_emb = false;
     double f64_switch = -1.0;   // share of occurrences on the float64 pass above which later steps use the float64 matrix alone (SAGE_F64_SWITCH; < 0: by kernel)
+    uint32_t match_threads = 1024;   // experiment: SAGE_MATCH_THREADS
     bool dots2 = true;     // k_dots2 (sage_kernels4.h) for the score kernel; SAGE_DOTS2=0 selects k_dots
     bool use_f32 = false;
     int score_mode = 0;   // 0 = float32 storage when lossless for most rows, 1 = always float64 storage
@@ -275,7 +276,7 @@ void launch_match_and_count(sage_ctx* c, const MatchBufs& B, int64_t line0, uint
         if (c->match_mode != 1) {
             const uint32_t pgrid = std::min<uint32_t>(cdiv(nb, 1024), (uint32_t)c->n_cu);
 #define SAGE_MATCH_LDS(NW_, ML_) do { \
-                if (c->match_mode == 0) k_match_lds<NW_, ML_, true><<<pgrid, 1024, 0, c->stream>>>(B.corpus, B.rem, pos0, (uint32_t)nb, v, B.M); \
+                if (c->match_mode == 0) k_match_lds<NW_, ML_, true><<<pgrid, c->match_threads, 0, c->stream>>>(B.corpus, B.rem, pos0, (uint32_t)nb, v, B.M); \
                 else k_match_lds<NW_, ML_, false><<<pgrid, 1024, 0, c->stream>>>(B.corpus, B.rem, pos0, (uint32_t)nb, v, B.M); } while (0)
             const int ml = c->max_len;      // the smallest instantiation that covers max_len
             if (ml <= 8) SAGE_MATCH_LDS(1, 8);
@@ -935,6 +936,7 @@ int sage_create(int device, sage_ctx** out_ctx) {
     }
     if (const char* e = std::getenv("SAGE_DEBUG_PART")) c->debug_part = std::atoi(e) != 0;
     if (const char* e = std::getenv("SAGE_DOTS2")) c->dots2 = std::atoi(e) != 0;
+    if (const char* e = std::getenv("SAGE_MATCH_THREADS")) { const int x = std::atoi(e); if (x >= 64 && x <= 1024 && x % 64 == 0) c->match_threads = (uint32_t)x; }
     if (const char* e = std::getenv("SAGE_F64_SWITCH")) { const double x = std::atof(e); if (x >= 0.0) c->f64_switch = x; }
     if (const char* e = std::getenv("SAGE_M_RESIDENT_MAX_GB")) { const long long x = std::atoll(e); if (x >= 0) c->m_resident_max = (int64_t)x << 30; }
     if (const char* e = std::getenv("SAGE_TEST_PAIR_LIMIT")) { const long long x = std::atoll(e); if (x > 0) c->pair_limit = (uint64_t)x; }

@@ -649,7 +649,7 @@ __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ 
     {
         const uint4* src4 = reinterpret_cast<const uint4*>(v.bloom);
         uint4* dst4 = reinterpret_cast<uint4*>(bloom);
-        for (uint32_t i = tid; i < SAGE_BLOOM_BITS / 128; i += 1024) dst4[i] = src4[i];
+        for (uint32_t i = tid; i < SAGE_BLOOM_BITS / 128; i += blockDim.x) dst4[i] = src4[i];
     }
     __syncthreads();
     // From here on the 16 waves of the block are independent: each sweeps its own 64-byte tiles and stages its text
@@ -658,8 +658,8 @@ __global__ __launch_bounds__(1024) void k_match_lds(const uint8_t* __restrict__ 
     const uint32_t lane = tid & 63u;
     uint32_t* text = text_all + (tid >> 6) * 32u;
     const uint32_t n_tiles = (count + 63u) / 64u;
-    const uint32_t stride = gridDim.x * 16u;
-    uint32_t tile = blockIdx.x * 16u + (tid >> 6);
+    const uint32_t stride = gridDim.x * (blockDim.x >> 6);
+    uint32_t tile = blockIdx.x * (blockDim.x >> 6) + (tid >> 6);
     uint32_t tw_n = 0, rm_n = 0;
     auto fetch = [&](uint32_t tl) {
         const int64_t b0 = pos0 + (int64_t)tl * 64;
