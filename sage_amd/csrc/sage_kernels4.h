@@ -26,6 +26,14 @@
 #pragma once
 
 #define DOTS2_HUGE 0x10000000u
+// Occurrences a group keeps asked for, the one it is in included (<= 8, the ring).  A ticket drawn early is an occurrence
+// processed long after its neighbours in the text, which other groups draw later -- and neighbours share window rows
+// that the L2 holds for a few microseconds only.  Measured per 300k lines (D = 50 / D = 300): 8 -> 4.48 / 21.1 ms, 6 -> 4.38,
+// 4 -> 4.26 / 20.4, 3 -> 4.16 / 20.2, 2 -> 4.09 / 21.4: the periods that run short of elements with a small value (the
+// top-up takes two periods) cost less than the re-fetched rows -- the kernel waits for its gathers, not for its lanes.
+#ifndef DOTS2_AHEAD
+#define DOTS2_AHEAD 3
+#endif
 
 template <int G, int EPL, typename T>
 __device__ __forceinline__ void load_row_at(const char* base, uint32_t off, T (&r)[EPL]) {
@@ -222,7 +230,7 @@ __device__ __forceinline__ void dots2_body(const uint4* __restrict__ desc, const
         }
         // (7) ask for as many occurrences as the ring has room for
         {
-            const uint32_t n_free = seq_cur + 8u - seq_req;
+            const uint32_t n_free = max((int)(seq_cur + (uint32_t)DOTS2_AHEAD - seq_req), 0);
             const uint32_t rel = (gl - seq_req) & 7u;
             const bool take = gl < 8u && rel < n_free;
             uint32_t base = 0;
