@@ -379,9 +379,10 @@ void launch_pairs(sage_ctx* c, const T* emb, const uint32_t* tok_w0, uint32_t n_
 // k_dots2 (sage_kernels4.h) addresses rows by 32-bit byte offsets: matrices under 4 GiB (every configuration of the survey)
 template <int G, int EPL, typename T, bool LIST>
 void launch_dots2(sage_ctx* c, const T* emb, uint32_t n_occ, const uint32_t* list, const uint32_t* list_count) {
-    // period: 6 elements (3 rows in flight); slices of 12 floats (D = 300) run better with 5 (21.2 against 22.9 ms per 300k
-    // lines, 159 registers at 6; k_dots: 22.0)
-    constexpr int P2 = EPL > 8 ? 5 : DOTS2_P;
+    // period: float32 slices of up to 8 elements plan 8 elements at a time (5 rows in flight: 3.96 ms per 300k lines against
+    // 4.12 with 6 at D = 50, and the same way at D = 20, 100, 200); slices of 12 floats (D = 300) run better with 5 (21.2
+    // against 22.9 with 6: 159 registers; k_dots: 22.0); float64 slices keep 6
+    constexpr int P2 = EPL > 8 ? 5 : (std::is_same<T, float>::value ? 8 : DOTS2_P);
     static std::atomic<int> cached{0};
     int per_cu = cached.load(std::memory_order_relaxed);
     if (per_cu == 0) {
