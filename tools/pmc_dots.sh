@@ -1,5 +1,6 @@
 #!/bin/bash
-# SQ counters of the score kernels on the 300k-line workload (run through gpurun from the repo root)
+# SQ counters of the step's kernels on the 300k-line workload (run through gpurun from the repo root; PMC="..." picks the
+# counters, at most 8 SQ_ ones; KERNELS=regex filters the kernels printed)
 set -o pipefail
 export TMPDIR=/tmp SB_WARM_MATCHES=1
 O=gpurun_out/pmc_dots
@@ -13,6 +14,7 @@ for r in csv.DictReader(open(f)):
     k = r['Kernel_Name'].split('(')[0][:40]
     agg[k][r['Counter_Name']] += float(r['Counter_Value'])
 for k, v in agg.items():
-    if 'dots' in k or 'logsig' in k:
+    import os, re
+    if re.search(os.environ.get('KERNELS', 'dots|logsig'), k):
         print(k, {c: f"{x:.3g}" for c, x in v.items()})
 PY
