@@ -1150,25 +1150,22 @@ __global__ __launch_bounds__(256) void k_logsig(const uint4* __restrict__ desc, 
                 else if (accf.lo | (unsigned long long)accf.hi) fix_atomic_add(&osum0[own], &osum1[own], accf);
                 acc = 0.0; accf = Fix128{0ull, 0};
             };
-            uint32_t q = 0;
-            for (; i < iend; ++i, ++q) {
+            auto one_dot = [&](double x) {
                 if (i >= nxt) {
                     hand_over();
                     do { ++own; nxt = off[own + 1]; } while (i >= nxt);
-                }
-                double x;
-                if (q < LOGSIG_PF) {
-                    x = v[0];
-#pragma unroll
-                    for (int z = 1; z < LOGSIG_PF; ++z) x = (q == (uint32_t)z) ? v[z] : x;
-                } else {
-                    x = dots[i];
                 }
                 const double ls = log_sigmoid(x);
                 if (!DET) acc += ls;
                 else if (fabs(ls) < FIX_LIMIT) fix_add(accf, fix_from(ls));
                 else stray(o0 + own, -2.0 * ls);
-            }
+            };
+            // the dots loaded ahead, each from its own register (picking v[q] by a run-time q costs 21 selects per dot), then
+            // the rest of a long slice from memory
+#pragma unroll
+            for (int q = 0; q < LOGSIG_PF; ++q)
+                if (i < iend) { one_dot(v[q]); ++i; }
+            for (; i < iend; ++i) one_dot(dots[i]);
             hand_over();
         }
         PH_MARK(4);
