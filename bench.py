@@ -446,6 +446,11 @@ def main():
                        "corpus_bytes_per_gpu": int(st["corpus_bytes"]), "total_tokens": total_tokens,
                        "total_triples": total_triples},
             "roofline": roofline_object(dom, avg_ms, launches_per_step, per_kernel_bytes, named_bytes, eb, args),
+            # the same object for the largest kernel that memory traffic does limit (when the largest of all is the matcher,
+            # whose algorithmic bytes say nothing about it: its `limiter` is the request rate of random 64-byte probes)
+            "roofline_largest_memory_bound_kernel": (lambda k2: roofline_object(
+                k2, kt[k2][0] / max(1, kt[k2][1]), max(1, kt[k2][1] // args.steps), per_kernel_bytes, named_bytes, eb, args))(
+                max((k for k in per_kernel_bytes if CLASS_BOUND.get(k) in ("hbm", "l2-fabric-gather")), key=lambda k: kt[k][0])),
             "unique_rows_per_32_occurrences": uniq,
             "step_roofline": {"measured_hbm_bytes_per_step": pmc_traffic("__step_total__", args) if world == 1 else None,
                               # the step's algorithmic bytes = the sum of its kernels' (kernel_roofline), per token of the shard
