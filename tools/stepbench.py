@@ -13,6 +13,12 @@ if os.environ.get("SB_SEED_OFF"):      # text of ANOTHER lexicon than the vocabu
     corpus, off = synth.make_corpus(N, seed=seed + int(os.environ["SB_SEED_OFF"]), style="en", n_types=1_000_000)
 else:
     corpus, off = synth.make_corpus(N, seed=seed, line_seed=int(os.environ.get("SB_LINE_SEED", "0")), style="en", n_types=1_000_000)
+if os.environ.get('SB_SPLIT_LONG'):     # timing experiment: lines longer than this many bytes are cut (how much of the walks is their longest line?)
+    T = int(os.environ['SB_SPLIT_LONG']); extra = []
+    for i in np.nonzero(np.diff(off) > T)[0]:
+        extra.extend(range(int(off[i]) + T, int(off[i + 1]), T))
+    off = np.sort(np.concatenate([off, np.array(extra, dtype=off.dtype)])); N = len(off) - 1
+    print("lines after the cut", N, "longest", int(np.diff(off).max()), flush=True)
 e = HipSage(0); e.set_vocab(vocab, None, 16); e.set_corpus(corpus, off)
 counts = np.bincount(e.tokenize(0, N)[0], minlength=len(vocab))
 unseen = ~(counts > 0)
