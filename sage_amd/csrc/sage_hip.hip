@@ -89,6 +89,8 @@ struct sage_ctx {
     // embeddings
     DevBuf emb;           // float64 rows (always kept: the exact values)
     DevBuf emb32;         // float32 rows, when most rows are float32-representable (word2vec output is)
+    DevBuf lline_list, lline_count;  // lines of more than SAGE_LONG_LINE bytes: walked a wave each (k_long_lines, once per corpus)
+    uint32_t n_lline = 0;            // how many (0 also with SAGE_LONG_WALK=0)
     DevBuf emb_stage, emb_cnt;   // sage_set_embeddings: the caller's contiguous matrix as uploaded; the count of inexact rows
     DevBuf inexact;       // bitmap of the rows that are not: their pairs are recomputed from `emb`
     DevBuf inex_list, inex_count;
@@ -98,6 +100,7 @@ struct sage_ctx {
     int dim = 0, dp = 0;
     bool have_emb = false;
     double f64_switch = -1.0;   // share of occurrences on the float64 pass above which later steps use the float64 matrix alone (SAGE_F64_SWITCH; < 0: by kernel)
+    bool long_walk = true;           // lines above SAGE_LONG_LINE bytes walked a wave each (SAGE_LONG_WALK=0: off)
     uint32_t match_threads = 1024;   // experiment: SAGE_MATCH_THREADS
     bool dots2 = true;     // k_dots2 (sage_kernels4.h) for the score kernel; SAGE_DOTS2=0 selects k_dots
     bool use_f32 = false;
@@ -261,6 +264,8 @@ struct MatchBufs {
     uint32_t* tile_sums;        // [scan_tiles(nl)]
     uint64_t* grand_total;      // [2]
     uint32_t* flags;            // [FLAG_COUNT]
+    const uint32_t* lline_list; // lines walked a wave each (k_long_lines), global line indices
+    uint32_t n_lline;           // 0: none, every line per thread
 };
 
 // K1 + K2a(count) + scans over the nl lines from line0 (nb text bytes from pos0): fills M, ntok/tokoff and nocc/occoff;
@@ -296,7 +301,8 @@ void launch_match_and_count(sage_ctx* c, const MatchBufs& B, int64_t line0, uint
     }
     {
         Prof p(c, SAGE_K_WALK);
-        k_walk_count<<<cdiv(nl, 256), 256, 0, c->stream>>>(B.line_off, line0, nl, pos0, B.M, B.ntok, B.nocc, B.flags);
+        k_walk_count<<<cdiv(nl, 256) + long_blocks(B.n_lline), 256, 0, c->stream>>>(B.line_off, line0, nl, pos0, B.M, B.ntok, B.nocc, B.flags,
+                                                                                     B.lline_list, B.n_lline);
     }
     scan_u32_with(c, B.ntok, nl, B.tokoff, B.grand_total, B.tile_sums);
     scan_u32_with(c, B.nocc, nl, B.occoff, B.grand_total + 1, B.tile_sums);
@@ -321,7 +327,8 @@ int match_and_count(sage_ctx* c, int64_t line0, int64_t line1, uint64_t* out_tot
     if ((rc = ensure(c, c->tile_sums, (size_t)scan_tiles(nl) * 4))) return rc;
     const MatchBufs B{c->corpus.as<uint8_t>(), c->rem.as<uint8_t>(), c->line_off.as<int64_t>(), batch_M(c, pos0),
                       c->ntok.as<uint32_t>(), c->nocc.as<uint32_t>(), c->tokoff.as<uint32_t>(), c->occoff.as<uint32_t>(),
-                      c->tile_sums.as<uint32_t>(), c->grand_total.as<uint64_t>(), c->flags.as<uint32_t>()};
+                      c->tile_sums.as<uint32_t>(), c->grand_total.as<uint64_t>(), c->flags.as<uint32_t>(),
+                      c->lline_list.as<uint32_t>(), c->n_lline};
     launch_match_and_count(c, B, line0, nl, pos0, c->m_valid ? 0 : nb);      // a valid M needs no matcher, only the walks
     HIP_TRY(c, hipGetLastError());
     if (out_total) {
@@ -585,10 +592,10 @@ int step_impl(sage_ctx* c, const int64_t* bounds, int64_t n_seg, int32_t pad, in
             if ((rc = ensure(c, c->occ_tok, (size_t)std::max(n_occ, 1u) * 4))) return rc;
             {
                 Prof p(c, SAGE_K_WALK);
-                k_walk_write<false><<<cdiv(nl, 256), 256, 0, c->stream>>>(
+                k_walk_write<false><<<cdiv(nl, 256) + long_blocks(c->n_lline), 256, 0, c->stream>>>(
                     c->line_off.as<int64_t>(), line0, nl, pos0, batch_M(c, pos0), c->tokoff.as<uint32_t>(),
                     c->occoff.as<uint32_t>(), c->tok_w0.as<uint32_t>(), c->occ_pos.as<uint32_t>(),
-                    c->occ_tok.as<uint32_t>(), nullptr, nullptr, nullptr);
+                    c->occ_tok.as<uint32_t>(), nullptr, nullptr, nullptr, c->lline_list.as<uint32_t>(), c->n_lline);
             }
             if (n_occ == 0) { HIP_TRY(c, hipGetLastError()); sa = sb; continue; }
             WalkArrays A{batch_M(c, pos0), (uint32_t)(c->h_line_off[line1] - pos0), c->tok_w0.as<uint32_t>(), c->occ_pos.as<uint32_t>(),
@@ -937,6 +944,7 @@ int sage_create(int device, sage_ctx** out_ctx) {
     }
     if (const char* e = std::getenv("SAGE_DEBUG_PART")) c->debug_part = std::atoi(e) != 0;
     if (const char* e = std::getenv("SAGE_DOTS2")) c->dots2 = std::atoi(e) != 0;
+    if (const char* e = std::getenv("SAGE_LONG_WALK")) c->long_walk = std::atoi(e) != 0;
     if (const char* e = std::getenv("SAGE_MATCH_THREADS")) { const int x = std::atoi(e); if (x >= 64 && x <= 1024 && x % 64 == 0) c->match_threads = (uint32_t)x; }
     if (const char* e = std::getenv("SAGE_F64_SWITCH")) { const double x = std::atof(e); if (x >= 0.0) c->f64_switch = x; }
     if (const char* e = std::getenv("SAGE_M_RESIDENT_MAX_GB")) { const long long x = std::atoll(e); if (x >= 0) c->m_resident_max = (int64_t)x << 30; }
@@ -954,7 +962,7 @@ void sage_destroy(sage_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     collect_events(c);
     for (auto e : c->ev_free) (void)hipEventDestroy(e);
-    DevBuf* all[] = {&c->buckets, &c->keys, &c->ebk, &c->parent, &c->parent_old, &c->old_to_new, &c->remap, &c->emb_stage, &c->emb_cnt, &c->vk_bytes, &c->vk_off, &c->vk_ids, &c->byte_id, &c->direct2, &c->bloom, &c->pmask, &c->pmask8, &c->corpus, &c->rem, &c->line_off, &c->emb, &c->M, &c->ntok,
+    DevBuf* all[] = {&c->buckets, &c->keys, &c->ebk, &c->parent, &c->parent_old, &c->old_to_new, &c->remap, &c->emb_stage, &c->emb_cnt, &c->lline_list, &c->lline_count, &c->vk_bytes, &c->vk_off, &c->vk_ids, &c->byte_id, &c->direct2, &c->bloom, &c->pmask, &c->pmask8, &c->corpus, &c->rem, &c->line_off, &c->emb, &c->M, &c->ntok,
                      &c->tokoff, &c->tile_sums, &c->grand_total, &c->tok_w0, &c->occ_pos, &c->set, &c->seg_line_rel,
                      &c->seg_tok_off, &c->set_base, &c->set_mask, &c->seg_pairs, &c->desc, &c->gcache, &c->bucket_off, &c->rec_a, &c->nocc, &c->occoff, &c->occ_tok,
                      &c->occ_a, &c->exact_list, &c->exact_count, &c->np_ab, &c->dot_off, &c->dots, &c->pool, &c->pool_cursor, &c->np_all, &c->pair_off, &c->seg_first_occ, &c->seg_tile_off,
@@ -1148,10 +1156,27 @@ int sage_set_corpus(sage_ctx* c, const uint8_t* bytes, const int64_t* line_offse
     c->nbytes = nbytes;
     c->m_valid = false;
     c->m_whole = nbytes > 0 && nbytes * 4 <= c->m_resident_max;
+    c->n_lline = 0;
     if (nbytes) {
         k_line_remaining<<<(uint32_t)std::min<uint64_t>(((uint64_t)nbytes + 255) / 256, 1u << 20), 256, 0, c->stream>>>(
             c->line_off.as<int64_t>(), n_lines, c->rem.as<uint8_t>(), nbytes);
         HIP_TRY(c, hipGetLastError());
+        if (c->long_walk) {      // the lines the walks take a wave each: counted, then listed
+            if ((rc = ensure(c, c->lline_count, 16))) return rc;
+            uint32_t n_long = 0;
+            HIP_TRY(c, hipMemsetAsync(c->lline_count.p, 0, 16, c->stream));
+            k_long_lines<<<cdiv((uint64_t)n_lines, 256), 256, 0, c->stream>>>(c->line_off.as<int64_t>(), n_lines, nullptr, c->lline_count.as<uint32_t>());
+            HIP_TRY(c, hipMemcpyAsync(&n_long, c->lline_count.p, 4, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (n_long) {
+                if ((rc = ensure(c, c->lline_list, (size_t)n_long * 4))) return rc;
+                HIP_TRY(c, hipMemsetAsync(c->lline_count.p, 0, 16, c->stream));
+                k_long_lines<<<cdiv((uint64_t)n_lines, 256), 256, 0, c->stream>>>(c->line_off.as<int64_t>(), n_lines, c->lline_list.as<uint32_t>(),
+                                                                                 c->lline_count.as<uint32_t>());
+                HIP_TRY(c, hipGetLastError());
+                c->n_lline = n_long;
+            }
+        }
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     c->have_corpus = true;
@@ -1212,10 +1237,10 @@ static int w2v_tokenize_batch(sage_ctx* c, int64_t l0, int64_t l1, uint32_t* n_t
     if ((rc = ensure(c, c->tok_w0, (size_t)n_tok * 4))) return rc;
     if ((rc = ensure(c, c->occ_pos, (size_t)std::max(n_occ, 1u) * 4))) return rc;
     if ((rc = ensure(c, c->occ_tok, (size_t)std::max(n_occ, 1u) * 4))) return rc;
-    k_walk_write<false><<<cdiv(nl, 256), 256, 0, c->stream>>>(
+    k_walk_write<false><<<cdiv(nl, 256) + long_blocks(c->n_lline), 256, 0, c->stream>>>(
         c->line_off.as<int64_t>(), l0, nl, c->h_line_off[l0], batch_M(c, c->h_line_off[l0]), c->tokoff.as<uint32_t>(),
         c->occoff.as<uint32_t>(), c->tok_w0.as<uint32_t>(), c->occ_pos.as<uint32_t>(), c->occ_tok.as<uint32_t>(),
-        nullptr, nullptr, nullptr);
+        nullptr, nullptr, nullptr, c->lline_list.as<uint32_t>(), c->n_lline);
     HIP_TRY(c, hipGetLastError());
     return SAGE_OK;
 }
@@ -1382,10 +1407,10 @@ int sage_tokenize(sage_ctx* c, int64_t line_begin, int64_t line_end, int32_t* ou
             if ((rc = ensure(c, c->ex_widths, ntok * 4))) return rc;
             {
                 Prof p(c, SAGE_K_WALK);
-                k_walk_write<true><<<cdiv(nl, 256), 256, 0, c->stream>>>(
+                k_walk_write<true><<<cdiv(nl, 256) + long_blocks(c->n_lline), 256, 0, c->stream>>>(
                     c->line_off.as<int64_t>(), l0, nl, c->h_line_off[l0], batch_M(c, c->h_line_off[l0]), c->tokoff.as<uint32_t>(),
                     nullptr, nullptr, nullptr, nullptr, c->ex_ids.as<int32_t>(), c->ex_starts.as<int32_t>(),
-                    c->ex_widths.as<int32_t>());
+                    c->ex_widths.as<int32_t>(), c->lline_list.as<uint32_t>(), c->n_lline);
             }
             HIP_TRY(c, hipGetLastError());
             HIP_TRY(c, hipMemcpyAsync(out_ids + total, c->ex_ids.p, ntok * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1434,7 +1459,7 @@ int sage_tokenize_noalloc(sage_ctx* c, const uint8_t* d_text, int64_t n_bytes, c
                       reinterpret_cast<uint32_t*>(S + NA_NTOK), reinterpret_cast<uint32_t*>(S + NA_NOCC),
                       reinterpret_cast<uint32_t*>(S + NA_TOKOFF), reinterpret_cast<uint32_t*>(S + NA_OCCOFF),
                       reinterpret_cast<uint32_t*>(S + NA_TILES), reinterpret_cast<uint64_t*>(S + NA_TOTAL),
-                      reinterpret_cast<uint32_t*>(S + NA_FLAGS)};
+                      reinterpret_cast<uint32_t*>(S + NA_FLAGS), nullptr, 0u};
     const uint32_t nl = (uint32_t)n_lines;
     // the array keeps the last call's contents: what must start at zero is cleared here (the text's pad, which the
     // matcher's 64-byte tiles read past the last byte, the totals and the flags); everything else is written before
@@ -1458,7 +1483,7 @@ int sage_tokenize_noalloc(sage_ctx* c, const uint8_t* d_text, int64_t n_bytes, c
             return fail(c, SAGE_E_ARG, "token capacity too small");
         }
         k_walk_write<true><<<cdiv(nl, 256), 256, 0, c->stream>>>(d_line_offsets, 0, nl, 0, B.M, B.tokoff, nullptr, nullptr,
-                                                                nullptr, nullptr, d_ids, d_starts, d_widths);
+                                                                nullptr, nullptr, d_ids, d_starts, d_widths, nullptr, 0u);
     }
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));

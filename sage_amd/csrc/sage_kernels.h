@@ -770,12 +770,75 @@ if constexpr (ML >= 9) {
 // K2a  base chain: one thread per line follows p -> p + len1(p) (model.py:89-99).  Pass 1 counts tokens, pass 2
 // (after an exclusive scan of the counts) writes the compact token arrays.
 // ----------------------------------------------------------------------------------------------------------
+// A walk is a chain of dependent loads (~0.3 us each), so a launch lasts as long as its longest line: 1,600 tokens in a
+// 9.5 KB line of the bench corpus outlast the other 300,000 lines of 500 bytes (1.61 ms for the two walks; 1.21 with no
+// line above 2 KB), and a 1 MB line of real text would take tens of milliseconds.  Lines of more than SAGE_LONG_LINE bytes
+// are therefore listed once per corpus (k_long_lines) and walked by the FIRST blocks of each walk launch, a WAVE per
+// line: it stages 512 entries of the match table in LDS at a time (coalesced loads) and one lane follows the chain there,
+// at LDS latency, beside the line-per-thread blocks, which skip the listed lines.  n_long = 0 switches the scheme off.
+#define SAGE_LONG_LINE 2048
+#define SAGE_LONG_CHUNK 512u
+__global__ __launch_bounds__(256) void k_long_lines(const int64_t* __restrict__ line_off, int64_t n_lines,
+                                                    uint32_t* __restrict__ list /* or nullptr: count only */, uint32_t* __restrict__ count) {
+    const int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (l >= n_lines) return;
+    if (line_off[l + 1] - line_off[l] > SAGE_LONG_LINE) {
+        const uint32_t at = atomicAdd(count, 1u);
+        if (list) list[at] = (uint32_t)l;
+    }
+}
+// blocks of a walk launch that take listed lines (4 waves = 4 lines each)
+static inline __host__ __device__ uint32_t long_blocks(uint32_t n_long) { return (n_long + 3u) / 4u; }
+// the listed line of this wave, relative to line0; false: none in this batch
+__device__ __forceinline__ bool long_line_of_wave(int64_t line0, uint32_t n_lines, const uint32_t* __restrict__ long_list,
+                                                  uint32_t n_long, uint32_t& l) {
+    const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (i >= n_long) return false;
+    const int64_t g = (int64_t)long_list[i];
+    if (g < line0 || g >= line0 + (int64_t)n_lines) return false;
+    l = (uint32_t)(g - line0);
+    return true;
+}
+// One chunk of a listed line's chain: the wave stages M[p, p + SAGE_LONG_CHUNK) (clipped to the line's end e) and lane 0
+// follows the chain while it stays inside; `each(m, p)` sees every token's entry.  Returns the position reached.
+template <class F>
+__device__ __forceinline__ uint32_t long_chunk(const uint32_t* __restrict__ M, uint32_t* buf, uint32_t p, uint32_t e, F&& each) {
+    const uint32_t lane = threadIdx.x & 63u, base = p;
+    __builtin_amdgcn_wave_barrier();                   // (lane 0 is done with the previous chunk)
+    for (uint32_t j = lane; j < SAGE_LONG_CHUNK && base + j < e; j += 64u) buf[j] = M[base + j];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0u) {
+        while (p < e && p - base < SAGE_LONG_CHUNK) {
+            const uint32_t m = buf[p - base];
+            each(m, p);
+            p += SAGE_M_LEN(m);
+        }
+    }
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
+}
+
 __global__ __launch_bounds__(256) void k_walk_count(const int64_t* __restrict__ line_off, int64_t line0,
                                                     uint32_t n_lines, int64_t pos0, const uint32_t* __restrict__ M,
                                                     uint32_t* __restrict__ ntok, uint32_t* __restrict__ nocc,
-                                                    uint32_t* __restrict__ flags) {
-    uint32_t l = blockIdx.x * 256u + threadIdx.x;
+                                                    uint32_t* __restrict__ flags,
+                                                    const uint32_t* __restrict__ long_list, uint32_t n_long) {
+    __shared__ uint32_t buf_all[4 * SAGE_LONG_CHUNK];
+    const uint32_t nlb = long_blocks(n_long);
+    if (blockIdx.x < nlb) {      // a listed line per wave
+        uint32_t ll;
+        if (!long_line_of_wave(line0, n_lines, long_list, n_long, ll)) return;
+        uint32_t* buf = buf_all + (threadIdx.x >> 6) * SAGE_LONG_CHUNK;
+        uint32_t q = (uint32_t)(line_off[line0 + ll] - pos0);
+        const uint32_t qe = (uint32_t)(line_off[line0 + ll + 1] - pos0);
+        uint32_t cc = 0, mm = 0;
+        while (q < qe) q = long_chunk(M, buf, q, qe, [&](uint32_t m, uint32_t) { ++cc; mm += SAGE_M_LEN(m) > 1u; });
+        if ((threadIdx.x & 63u) == 0u) { ntok[ll] = cc; nocc[ll] = mm; }
+        return;
+    }
+    uint32_t l = (blockIdx.x - nlb) * 256u + threadIdx.x;
     if (l >= n_lines) return;
+    if (n_long != 0u && line_off[line0 + l + 1] - line_off[line0 + l] > SAGE_LONG_LINE) return;     // a listed line
     uint32_t p = (uint32_t)(line_off[line0 + l] - pos0), e = (uint32_t)(line_off[line0 + l + 1] - pos0);
     if (p == e) flags[FLAG_EMPTY_LINE] = 1;
     uint32_t c = 0, mb = 0;
@@ -823,9 +886,38 @@ __global__ __launch_bounds__(256) void k_walk_write(const int64_t* __restrict__ 
                                                     uint32_t* __restrict__ tok_w0, uint32_t* __restrict__ occ_pos,
                                                     uint32_t* __restrict__ occ_tok,
                                                     int32_t* __restrict__ ex_ids, int32_t* __restrict__ ex_starts,
-                                                    int32_t* __restrict__ ex_widths) {
-    uint32_t l = blockIdx.x * 256u + threadIdx.x;
+                                                    int32_t* __restrict__ ex_widths,
+                                                    const uint32_t* __restrict__ long_list, uint32_t n_long) {
+    __shared__ uint32_t buf_all[4 * SAGE_LONG_CHUNK];
+    const uint32_t nlb = long_blocks(n_long);
+    if (blockIdx.x < nlb) {      // a listed line per wave: the same words, written one by one by the lane that follows the chain
+        uint32_t ll;
+        if (!long_line_of_wave(line0, n_lines, long_list, n_long, ll)) return;
+        uint32_t* buf = buf_all + (threadIdx.x >> 6) * SAGE_LONG_CHUNK;
+        const uint32_t q_begin = (uint32_t)(line_off[line0 + ll] - pos0);
+        uint32_t q = q_begin;
+        const uint32_t qe = (uint32_t)(line_off[line0 + ll + 1] - pos0);
+        uint32_t tt = tok_off[ll], cc = 0;
+        const uint32_t ntt = tok_off[ll + 1] - tt;
+        uint32_t oo = EXPORT ? 0u : occ_off[ll];
+        while (q < qe)
+            q = long_chunk(M, buf, q, qe, [&](uint32_t m, uint32_t at) {
+                if (EXPORT) {
+                    ex_ids[tt] = (int32_t)SAGE_M_ID(m);
+                    ex_starts[tt] = (int32_t)(at - q_begin);
+                    ex_widths[tt] = (int32_t)SAGE_M_LEN(m);
+                } else {
+                    const uint32_t after = ntt - 1u - cc;
+                    tok_w0[tt] = SAGE_M_ID(m) | ((cc < 3u ? cc : 3u) << 20) | ((after < 3u ? after : 3u) << 22) | (SAGE_M_LEN(m) << 24);
+                    if (SAGE_M_LEN(m) > 1u) { occ_tok[oo] = tt; occ_pos[oo] = at; ++oo; }
+                }
+                ++tt; ++cc;
+            });
+        return;
+    }
+    uint32_t l = (blockIdx.x - nlb) * 256u + threadIdx.x;
     if (l >= n_lines) return;
+    if (n_long != 0u && line_off[line0 + l + 1] - line_off[line0 + l] > SAGE_LONG_LINE) return;     // a listed line
     const uint32_t p_begin = (uint32_t)(line_off[line0 + l] - pos0);
     uint32_t p = p_begin, e = (uint32_t)(line_off[line0 + l + 1] - pos0);
     uint32_t t = tok_off[l], c = 0;

@@ -638,3 +638,52 @@ def test_score_kernels_agree_on_short_windows(score_mode, monkeypatch):
     np.testing.assert_allclose(l1, l0, rtol=1e-12, atol=1e-12 * scale)
     if score_mode == 1:
         np.testing.assert_array_equal(l1, l0)      # one kernel pair, the same sums: bit for bit
+
+
+def test_long_lines_walked_in_lds(monkeypatch):
+    """Lines of more than 2 KB are walked by a wave that stages the match table in LDS (the first blocks of k_walk_count /
+    k_walk_write), all others by a thread each.  A corpus with lines of 5 KB to 300 KB among short ones (chains that step
+    over many chunk ends), and one with 2,100 long lines: tokenization (ids, starts, widths), token counts and the whole
+    step, over several batches, equal to the same library with SAGE_LONG_WALK=0."""
+    from sage_amd import synth
+    from sage_amd.parallel import segment_line_bounds
+    base, boff = synth.make_corpus(3000, seed=91, style="en", n_types=20_000)
+    vocab = synth.make_vocab(base, boff, 6000, 16, sample_bytes=1_000_000)
+    short = synth.corpus_lines(base, boff)
+    rs = np.random.RandomState(4)
+
+    def corpus_with(n_long, words_per_long):
+        lines, at = [], 0
+        for i in range(n_long):
+            k = int(words_per_long[i % len(words_per_long)])
+            lines.append(" ".join(short[(at + j) % len(short)] for j in range(k)))
+            at += k
+            lines.extend(short[(at + j) % len(short)] for j in range(int(rs.randint(0, 4))))
+        return lines + short[:500]
+    cases = [corpus_with(12, [12, 40, 600, 9, 120]),        # 5 KB .. 300 KB
+             corpus_with(2100, [9, 10, 11])]                 # many listed lines
+    for lines in cases:
+        corpus, off = _pack(lines)
+        assert int(np.diff(off).max()) > 4096
+        res = []
+        for flag in ("1", "0"):
+            monkeypatch.setenv("SAGE_LONG_WALK", flag)
+            eng = _engine()
+            eng.set_deterministic(True)
+            eng.set_vocab(vocab, None, 16)
+            eng.set_corpus(corpus, off)
+            tok = eng.tokenize(0, len(lines))
+            counts = np.bincount(tok[0], minlength=len(vocab))
+            emb = synth.make_embeddings(len(vocab), 50, seed=3, unseen=~(counts > 0))
+            eng.set_embeddings(emb)
+            eng.set_batch_bytes(1 << 20)                      # several batches: listed lines belong to one of them each
+            res.append((tok, eng.token_counts(0, len(lines)), eng.ablation_step(segment_line_bounds(len(lines), 3))))
+            eng.close()
+        (t1, c1, s1), (t0, c0, s0) = res
+        for a, b in zip(t1, t0):
+            np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(c1[0], c0[0])
+        assert c1[1] == c0[1] and s1[2:4] == s0[2:4]
+        np.testing.assert_array_equal(s1[0], s0[0])
+        np.testing.assert_array_equal(s1[1], s0[1])
+        np.testing.assert_array_equal(s1[4], s0[4])
